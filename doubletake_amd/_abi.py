@@ -1,0 +1,91 @@
+"""ctypes binding of include/doubletake_hip.h.
+
+The product path has no CPU fallback: if the shared library is missing or a call fails this
+raises.  (Importing this module does not need a GPU; launching kernels does.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+_lib = None
+
+
+class DoubletakeHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "n", "h_out", "w_out", "c_out", "ca", "cb", "up_a", "up_b", "ksize", "stride", "act", "h_in", "w_in")]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+
+# name -> (restype, argtypes); mirrors include/doubletake_hip.h declaration by declaration
+SIGNATURES = {
+    "dt_version": (_I, []),
+    "dt_last_error": (C.c_char_p, []),
+    "dt_device_count": (_I, []),
+    "dt_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dt_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dt_cv_params_floats": (_I, [_I, _I]),
+    "dt_cv_setup_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "dt_cv_dot_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dt_cv_mlp_pack_floats": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "dt_cv_mlp_hint_f32": (_I, [_P] * 11 + [_I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dt_cv_mlp_hint_simple_f32": (_I, [_P] * 13 + [_I, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "dt_cv_lowest_cost_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dt_cv_overall_mask_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+}
+
+
+def lib():
+    """Load (building first if the sources changed and hipcc is available) and return the CDLL."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not _build.is_current():
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # no hipcc / compile error
+            if not os.path.isfile(path):
+                raise DoubletakeHipError(
+                    f"libdoubletake_hip.so is not built and cannot be built here ({e}). "
+                    "Run `python -m doubletake_amd._build` where hipcc is available."
+                ) from e
+            raise
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first so both sides share one HIP runtime)
+    except Exception:
+        pass
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().dt_last_error().decode(errors="replace")
+        raise DoubletakeHipError(f"{what}: {msg}" if what else msg)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,347 @@
+// Plane-sweep cost volume: setup, dot-product volume, simple (cross-check) MLP volume,
+// lowest-cost and overall-mask kernels.  gfx950 only.
+//
+// Reference behaviour restated here (paths relative to /root/reference/src/doubletake/):
+//   CostVolumeManager.generate_depth_planes   modules/cost_volume.py:96-130
+//   CostVolumeManager.warp_features           modules/cost_volume.py:132-217
+//   CostVolumeManager.build_cost_volume       modules/cost_volume.py:219-315
+//   CostVolumeManager.forward (argmax/gather) modules/cost_volume.py:355-361
+//   CostVolumeManager.get_mask                modules/cost_volume.py:73-94
+//   pose_distance                             utils/geometry_utils.py:187-199
+//   FeatureMeshHintVolumeManager.build_cost_volume modules/mesh_hint_volume.py:84-393
+#include "common.hpp"
+#include "cv_geometry.hpp"
+
+namespace dt {
+
+// ------------------------------------------------------------------------------------------
+// setup: one block per batch element, thread k handles source view k; thread-strided planes
+// ------------------------------------------------------------------------------------------
+__global__ void cv_setup_kernel(const float* __restrict__ src_Ks, const float* __restrict__ src_ext,
+                                const float* __restrict__ src_poses, const float* __restrict__ cur_invK,
+                                const float* __restrict__ min_depth, const float* __restrict__ max_depth,
+                                int K, int D, float* __restrict__ params) {
+  const int b = blockIdx.x;
+  float* p = params + (size_t)b * cv_params_floats(D, K);
+  const int t = threadIdx.x;
+  if (t < 12) {
+    // invK[:3,:3] row-major (pad with zeros)
+    float v = 0.f;
+    if (t < 9) v = cur_invK[b * 16 + (t / 3) * 4 + (t % 3)];
+    p[kCvInvK + t] = v;
+  }
+  const float mn = min_depth[b], mx = max_depth[b];
+  const float lmn = logf(mn), lr = logf(mx / mn);
+  for (int d = t; d < D; d += blockDim.x) {
+    const float ramp = (D > 1) ? (float)d / (float)(D - 1) : 0.f;
+    p[kCvPlanes + d] = expf(lmn + lr * ramp);
+  }
+  for (int k = t; k < K; k += blockDim.x) {
+    const float* Km = src_Ks + ((size_t)b * K + k) * 16;
+    const float* E = src_ext + ((size_t)b * K + k) * 16;
+    const float* T = src_poses + ((size_t)b * K + k) * 16;
+    float* v = p + cv_view_off(D, k);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 4; ++j) {
+        float acc = 0.f;
+        for (int m = 0; m < 4; ++m) acc += Km[i * 4 + m] * E[m * 4 + j];
+        v[i * 4 + j] = acc;
+      }
+    const float tx = T[3], ty = T[7], tz = T[11];
+    v[12] = tx;
+    v[13] = ty;
+    v[14] = tz;
+    const float tr = T[0] + T[5] + T[10];
+    const float Rm = sqrtf(2.f * (1.f - fminf(3.f, tr) / 3.f));
+    const float tm = sqrtf(tx * tx + ty * ty + tz * tz);
+    v[15] = sqrtf(tm * tm + Rm * Rm);
+    v[16] = Rm;
+    v[17] = tm;
+    v[18] = 0.f;
+    v[19] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dot-product volume.  One thread per pixel of a 32x8 tile, PC planes per block.
+// Source features are NHWC so one bilinear tap = C contiguous floats (float4 loads).
+// ------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void cv_dot_kernel(const float* __restrict__ cur_bchw,
+                                                     const float* __restrict__ src_bkhwc,
+                                                     const float* __restrict__ params,
+                                                     float* __restrict__ vol, int K, int h, int w, int D,
+                                                     int planes_per_block) {
+  const int b = blockIdx.z;
+  const int tiles_x = (w + 31) / 32;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x = tx * 32 + (threadIdx.x & 31), y = ty * 8 + (threadIdx.x >> 5);
+  const bool live = (x < w) && (y < h);
+  const int xc = min(x, w - 1), yc = min(y, h - 1);
+  const float* p = params + (size_t)b * cv_params_floats(D, K);
+  const size_t hw = (size_t)h * w;
+
+  float cur[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) cur[c] = cur_bchw[((size_t)b * C + c) * hw + (size_t)yc * w + xc];
+  float rx, ry, rz;
+  pixel_ray(p + kCvInvK, xc, yc, rx, ry, rz);
+  const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
+
+  const int d0 = blockIdx.y * planes_per_block;
+  const int d1 = min(d0 + planes_per_block, D);
+  for (int d = d0; d < d1; ++d) {
+    const float depth = p[kCvPlanes + d];
+    const float X = depth * rx, Y = depth * ry, Z = depth * rz;
+    float total = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float* vp = p + cv_view_off(D, k);
+      const ViewProj q = project_view(vp, X, Y, Z);
+      const Taps t = bilinear_taps(q.u, q.v, h, w, inv_w, inv_h);
+      const float* base = src_bkhwc + ((size_t)b * K + k) * hw * C;
+      const float4* p00 = reinterpret_cast<const float4*>(base + ((size_t)t.y0 * w + t.x0) * C);
+      const float4* p01 = reinterpret_cast<const float4*>(base + ((size_t)t.y0 * w + t.x1) * C);
+      const float4* p10 = reinterpret_cast<const float4*>(base + ((size_t)t.y1 * w + t.x0) * C);
+      const float4* p11 = reinterpret_cast<const float4*>(base + ((size_t)t.y1 * w + t.x1) * C);
+      float dot = 0.f;
+#pragma unroll
+      for (int c4 = 0; c4 < C / 4; ++c4) {
+        const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
+        const float f0 = a.x * t.w00 + bq.x * t.w01 + cq.x * t.w10 + dq.x * t.w11;
+        const float f1 = a.y * t.w00 + bq.y * t.w01 + cq.y * t.w10 + dq.y * t.w11;
+        const float f2 = a.z * t.w00 + bq.z * t.w01 + cq.z * t.w10 + dq.z * t.w11;
+        const float f3 = a.w * t.w00 + bq.w * t.w01 + cq.w * t.w10 + dq.w * t.w11;
+        dot += f0 * cur[c4 * 4 + 0] + f1 * cur[c4 * 4 + 1] + f2 * cur[c4 * 4 + 2] + f3 * cur[c4 * 4 + 3];
+      }
+      total += (q.z > 0.f) ? dot : 0.f;
+    }
+    if (live) vol[((size_t)b * D + d) * hw + (size_t)y * w + x] = total;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// simple MLP / hint volume: one thread per (pixel, plane); everything in plain fp32 loops.
+// Input-vector channel order follows modules/mesh_hint_volume.py:353-370.
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxSrc = 8;
+constexpr int kFeat = 16;
+constexpr int kHidden = 128;
+
+__global__ __launch_bounds__(128) void cv_mlp_simple_kernel(
+    const float* __restrict__ cur_bchw, const float* __restrict__ src_bkhwc, const float* __restrict__ params,
+    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+    const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
+    const float* __restrict__ hint_mlp, const float* __restrict__ depth_hint, const float* __restrict__ hint_w,
+    const float* __restrict__ hint_m, int hint_h, int hint_w2, float* __restrict__ vol, int K, int h, int w, int D) {
+  const int b = blockIdx.z;
+  const int d = blockIdx.y;
+  const size_t hw = (size_t)h * w;
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= hw) return;
+  const int y = (int)(pix / w), x = (int)(pix % w);
+  const float* p = params + (size_t)b * cv_params_floats(D, K);
+  const int Cin = 20 * (K + 1) + 6 * K;
+
+  float in[20 * (kMaxSrc + 1) + 6 * kMaxSrc];
+  float rx, ry, rz;
+  pixel_ray(p + kCvInvK, x, y, rx, ry, rz);
+  const float depth = p[kCvPlanes + d];
+  const float X = depth * rx, Y = depth * ry, Z = depth * rz;
+  float cx = X, cy = Y, cz = Z;
+  normalize3(cx, cy, cz);
+  const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
+
+  const int o_cur = kFeat * K, o_mask = o_cur + kFeat, o_z = o_mask + K, o_plane = o_z + K;
+  const int o_dot = o_plane + 1, o_ang = o_dot + K, o_cray = o_ang + K, o_sray = o_cray + 3;
+  const int o_pd = o_sray + 3 * K, o_R = o_pd + K, o_t = o_R + K;
+
+  for (int c = 0; c < kFeat; ++c) in[o_cur + c] = cur_bchw[((size_t)b * kFeat + c) * hw + pix];
+  in[o_plane] = depth;
+  in[o_cray + 0] = cx;
+  in[o_cray + 1] = cy;
+  in[o_cray + 2] = cz;
+  for (int k = 0; k < K; ++k) {
+    const float* vp = p + cv_view_off(D, k);
+    const ViewProj q = project_view(vp, X, Y, Z);
+    const Taps t = bilinear_taps(q.u, q.v, h, w, inv_w, inv_h);
+    const float* base = src_bkhwc + ((size_t)b * K + k) * hw * kFeat;
+    const float* p00 = base + ((size_t)t.y0 * w + t.x0) * kFeat;
+    const float* p01 = base + ((size_t)t.y0 * w + t.x1) * kFeat;
+    const float* p10 = base + ((size_t)t.y1 * w + t.x0) * kFeat;
+    const float* p11 = base + ((size_t)t.y1 * w + t.x1) * kFeat;
+    float dot = 0.f;
+    for (int c = 0; c < kFeat; ++c) {
+      const float f = p00[c] * t.w00 + p01[c] * t.w01 + p10[c] * t.w10 + p11[c] * t.w11;
+      in[k * kFeat + c] = f;
+      dot += f * in[o_cur + c];
+    }
+    const float m = (q.z > 0.f) ? 1.f : 0.f;
+    in[o_mask + k] = m;
+    in[o_z + k] = q.z;
+    in[o_dot + k] = dot * m;
+    float sx = X - vp[12], sy = Y - vp[13], sz = Z - vp[14];
+    normalize3(sx, sy, sz);
+    in[o_ang + k] = cos_sim3(cx, cy, cz, sx, sy, sz);
+    in[o_sray + 3 * k + 0] = sx;
+    in[o_sray + 3 * k + 1] = sy;
+    in[o_sray + 3 * k + 2] = sz;
+    in[o_pd + k] = vp[15];
+    in[o_R + k] = vp[16];
+    in[o_t + k] = vp[17];
+  }
+
+  float h1[kHidden];
+  for (int j = 0; j < kHidden; ++j) {
+    float acc = b1[j];
+    const float* wr = W1 + (size_t)j * Cin;
+    for (int c = 0; c < Cin; ++c) acc += wr[c] * in[c];
+    h1[j] = lrelu(acc, 0.01f);
+  }
+  float s = b3[0];
+  for (int j = 0; j < kHidden; ++j) {
+    float acc = b2[j];
+    const float* wr = W2 + (size_t)j * kHidden;
+    for (int c = 0; c < kHidden; ++c) acc += wr[c] * h1[c];
+    s += W3[j] * lrelu(acc, 0.01f);
+  }
+  if (hint_mlp != nullptr) {
+    const int sy = nearest_src(y, hint_h, h), sx = nearest_src(x, hint_w2, w);
+    const size_t hi = ((size_t)b * hint_h + sy) * hint_w2 + sx;
+    const bool m = hint_m[hi] != 0.f;
+    const float hint = m ? fabsf(depth_hint[hi] - depth) : -1.f;
+    const float hwt = m ? hint_w[hi] : 0.f;
+    s = hint_mlp_eval(hint_mlp, s, hint, hwt);
+  }
+  vol[((size_t)b * D + d) * hw + pix] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// lowest cost: plane depth at the first maximum over d
+// ------------------------------------------------------------------------------------------
+__global__ void cv_lowest_cost_kernel(const float* __restrict__ vol, const float* __restrict__ params,
+                                      float* __restrict__ out, int nhwc, int K, size_t hw, int D) {
+  const int b = blockIdx.y;
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= hw) return;
+  const float* p = params + (size_t)b * cv_params_floats(D, K);
+  float best = -INFINITY;
+  int bi = 0;
+  bool seen_nan = false;
+  for (int d = 0; d < D; ++d) {
+    const float v = nhwc ? vol[((size_t)b * hw + pix) * D + d] : vol[((size_t)b * D + d) * hw + pix];
+    // torch.argmax treats NaN as the maximum (first NaN wins)
+    if (!seen_nan && (v != v)) {
+      seen_nan = true;
+      bi = d;
+    }
+    if (!seen_nan && v > best) {
+      best = v;
+      bi = d;
+    }
+  }
+  out[(size_t)b * hw + pix] = p[kCvPlanes + bi];
+}
+
+// ------------------------------------------------------------------------------------------
+// overall mask at the last plane
+// ------------------------------------------------------------------------------------------
+__global__ void cv_mask_kernel(const float* __restrict__ params, uint8_t* __restrict__ out, int per_view,
+                               int K, int h, int w, int D) {
+  const int b = blockIdx.y;
+  const size_t hw = (size_t)h * w;
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= hw) return;
+  const int y = (int)(pix / w), x = (int)(pix % w);
+  const float* p = params + (size_t)b * cv_params_floats(D, K);
+  float rx, ry, rz;
+  pixel_ray(p + kCvInvK, x, y, rx, ry, rz);
+  const float depth = p[kCvPlanes + D - 1];
+  const float X = depth * rx, Y = depth * ry, Z = depth * rz;
+  bool any_d = false, any_b = false;
+  for (int k = 0; k < K; ++k) {
+    const ViewProj q = project_view(p + cv_view_off(D, k), X, Y, Z);
+    const bool dm = q.z > 0.f;
+    const bool bm = (q.u > 2.f) && (q.u < (float)(w - 2)) && (q.v > 2.f) && (q.v < (float)(h - 2));
+    any_d |= dm;
+    any_b |= bm;
+    if (per_view) out[((size_t)b * K + k) * hw + pix] = (dm && bm) ? 1 : 0;
+  }
+  if (!per_view) out[(size_t)b * hw + pix] = (any_d && any_b) ? 1 : 0;
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+extern "C" {
+
+int dt_cv_params_floats(int num_planes, int num_src) { return cv_params_floats(num_planes, num_src); }
+
+int dt_cv_setup_f32(const float* src_Ks, const float* src_ext, const float* src_poses, const float* cur_invK,
+                    const float* min_depth, const float* max_depth, int batch, int num_src, int num_planes,
+                    float* params_out, dt_stream_t s) {
+  DT_REQUIRE(batch > 0 && num_src > 0 && num_planes > 0, "dt_cv_setup_f32: bad extents b=%d k=%d D=%d", batch,
+             num_src, num_planes);
+  DT_REQUIRE(src_Ks && src_ext && src_poses && cur_invK && min_depth && max_depth && params_out,
+             "dt_cv_setup_f32: null pointer");
+  hipLaunchKernelGGL(cv_setup_kernel, dim3(batch), dim3(64), 0, to_stream(s), src_Ks, src_ext, src_poses, cur_invK,
+                     min_depth, max_depth, num_src, num_planes, params_out);
+  return check_launch("dt_cv_setup_f32");
+}
+
+int dt_cv_dot_f32(const float* cur, const float* src, const float* params, float* vol, int batch, int num_src,
+                  int channels, int h, int w, int num_planes, dt_stream_t s) {
+  DT_REQUIRE(batch > 0 && num_src > 0 && h > 0 && w > 0 && num_planes > 0, "dt_cv_dot_f32: bad extents");
+  DT_REQUIRE(channels == 16, "dt_cv_dot_f32: channels=%d unsupported (matching_feature_dims must be 16)", channels);
+  DT_REQUIRE(cur && src && params && vol, "dt_cv_dot_f32: null pointer");
+  const int tiles = ((w + 31) / 32) * ((h + 7) / 8);
+  // enough blocks to fill 256 CUs: split planes until >= ~1024 blocks or 4 planes per block
+  int ppb = num_planes;
+  while (ppb > 4 && (long)tiles * batch * ((num_planes + ppb - 1) / ppb) < 1024) ppb = (ppb + 1) / 2;
+  dim3 grid(tiles, (num_planes + ppb - 1) / ppb, batch);
+  hipLaunchKernelGGL(cv_dot_kernel<16>, grid, dim3(256), 0, to_stream(s), cur, src, params, vol, num_src, h, w,
+                     num_planes, ppb);
+  return check_launch("dt_cv_dot_f32");
+}
+
+int dt_cv_mlp_hint_simple_f32(const float* cur, const float* src, const float* params, const float* W1,
+                              const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                              const float* hint_mlp, const float* depth_hint, const float* hint_w,
+                              const float* hint_m, int hint_h, int hint_w2, float* vol, int batch, int num_src, int h, int w,
+                              int num_planes, dt_stream_t s) {
+  DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0, "dt_cv_mlp_hint_simple_f32: bad extents");
+  DT_REQUIRE(num_src > 0 && num_src <= kMaxSrc, "dt_cv_mlp_hint_simple_f32: num_src=%d not in 1..%d", num_src,
+             kMaxSrc);
+  DT_REQUIRE(cur && src && params && W1 && b1 && W2 && b2 && W3 && b3 && vol, "dt_cv_mlp_hint_simple_f32: null pointer");
+  DT_REQUIRE(hint_mlp == nullptr || (depth_hint && hint_w && hint_m && hint_h > 0 && hint_w2 > 0),
+             "dt_cv_mlp_hint_simple_f32: hint MLP given without hint maps");
+  const size_t hw = (size_t)h * w;
+  dim3 grid((unsigned)((hw + 127) / 128), num_planes, batch);
+  hipLaunchKernelGGL(cv_mlp_simple_kernel, grid, dim3(128), 0, to_stream(s), cur, src, params, W1, b1, W2, b2, W3, b3,
+                     hint_mlp, depth_hint, hint_w, hint_m, hint_h, hint_w2, vol, num_src, h, w, num_planes);
+  return check_launch("dt_cv_mlp_hint_simple_f32");
+}
+
+int dt_cv_lowest_cost_f32(const float* volume, const float* params, float* lowest, int nhwc, int batch, int num_src,
+                          int h, int w, int num_planes, dt_stream_t s) {
+  DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0 && num_src > 0, "dt_cv_lowest_cost_f32: bad extents");
+  DT_REQUIRE(volume && params && lowest, "dt_cv_lowest_cost_f32: null pointer");
+  const size_t hw = (size_t)h * w;
+  dim3 grid((unsigned)((hw + 255) / 256), batch);
+  hipLaunchKernelGGL(cv_lowest_cost_kernel, grid, dim3(256), 0, to_stream(s), volume, params, lowest, nhwc, num_src, hw,
+                     num_planes);
+  return check_launch("dt_cv_lowest_cost_f32");
+}
+
+int dt_cv_overall_mask_u8(const float* params, uint8_t* mask_out, int per_view, int batch, int num_src, int h, int w,
+                          int num_planes, dt_stream_t s) {
+  DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0 && num_src > 0, "dt_cv_overall_mask_u8: bad extents");
+  DT_REQUIRE(params && mask_out, "dt_cv_overall_mask_u8: null pointer");
+  const size_t hw = (size_t)h * w;
+  dim3 grid((unsigned)((hw + 255) / 256), batch);
+  hipLaunchKernelGGL(cv_mask_kernel, grid, dim3(256), 0, to_stream(s), params, mask_out, per_view, num_src, h, w,
+                     num_planes);
+  return check_launch("dt_cv_overall_mask_u8");
+}
+
+}  // extern "C"

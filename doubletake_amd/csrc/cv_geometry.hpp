@@ -1,0 +1,118 @@
+// Per-pixel plane-sweep geometry shared by the cost-volume kernels.
+//
+// Restates (does not copy) the reference arithmetic:
+//   BackprojectDepth      utils/geometry_utils.py:34-39,60-63   pix=(x+.5,y+.5,1); X = d*(invK3@pix)
+//   Project3D             utils/geometry_utils.py:82-93         q = P@(X,1); z' = q.z+eps; uv = q.xy*(|q.z|>eps ? 1/z' : 1)
+//   grid normalisation    modules/cost_volume.py:186            g = 2*uv*(1/w,1/h) - 1
+//   F.grid_sample         bilinear / zeros / align_corners=False: idx = ((g+1)*size-1)/2, taps floor/floor+1
+#pragma once
+#include "common.hpp"
+
+namespace dt {
+
+struct ViewProj {
+  float u, v, z;  // source pixel coords (pixel centres at +0.5) and z' = depth + eps
+};
+
+// cam ray r = invK3 @ (x+0.5, y+0.5, 1)
+__device__ __forceinline__ void pixel_ray(const float* __restrict__ invK3, int x, int y, float& rx,
+                                          float& ry, float& rz) {
+  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+  rx = invK3[0] * px + invK3[1] * py + invK3[2];
+  ry = invK3[3] * px + invK3[4] * py + invK3[5];
+  rz = invK3[6] * px + invK3[7] * py + invK3[8];
+}
+
+__device__ __forceinline__ ViewProj project_view(const float* __restrict__ P, float X, float Y, float Z) {
+  const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
+  const float qy = P[4] * X + P[5] * Y + P[6] * Z + P[7];
+  const float qz = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+  ViewProj r;
+  r.z = qz + 1e-8f;
+  const float s = (fabsf(qz) > 1e-8f) ? (1.0f / r.z) : 1.0f;
+  r.u = qx * s;
+  r.v = qy * s;
+  return r;
+}
+
+// Bilinear tap set for one sample: base texel (x0,y0), 4 weights already zeroed for
+// out-of-bounds taps, and clamped in-bounds addresses so that loads are always legal.
+struct Taps {
+  int x0, y0, x1, y1;         // clamped to the image
+  float w00, w01, w10, w11;   // (y0,x0) (y0,x1) (y1,x0) (y1,x1); 0 where the tap is outside
+};
+
+__device__ __forceinline__ Taps bilinear_taps(float u, float v, int h, int w, float inv_w, float inv_h) {
+  const float gx = 2.0f * u * inv_w - 1.0f;
+  const float gy = 2.0f * v * inv_h - 1.0f;
+  const float ix = ((gx + 1.0f) * (float)w - 1.0f) * 0.5f;
+  const float iy = ((gy + 1.0f) * (float)h - 1.0f) * 0.5f;
+  Taps t;
+  // anything that cannot touch the image (incl. NaN/inf) samples zero
+  const bool any = (ix > -1.0f) && (ix < (float)w) && (iy > -1.0f) && (iy < (float)h);
+  const float fx = any ? floorf(ix) : 0.0f;
+  const float fy = any ? floorf(iy) : 0.0f;
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = any ? ix - fx : 0.0f, wy1 = any ? iy - fy : 0.0f;
+  const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+  const bool vx0 = any && x0 >= 0, vx1 = any && (x0 + 1) < w;
+  const bool vy0 = any && y0 >= 0, vy1 = any && (y0 + 1) < h;
+  t.w00 = (vx0 && vy0) ? wx0 * wy0 : 0.0f;
+  t.w01 = (vx1 && vy0) ? wx1 * wy0 : 0.0f;
+  t.w10 = (vx0 && vy1) ? wx0 * wy1 : 0.0f;
+  t.w11 = (vx1 && vy1) ? wx1 * wy1 : 0.0f;
+  t.x0 = min(max(x0, 0), w - 1);
+  t.x1 = min(max(x0 + 1, 0), w - 1);
+  t.y0 = min(max(y0, 0), h - 1);
+  t.y1 = min(max(y0 + 1, 0), h - 1);
+  return t;
+}
+
+// F.normalize(dim): v / max(||v||, 1e-12)
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+  const float n = sqrtf(x * x + y * y + z * z);
+  const float inv = 1.0f / fmaxf(n, 1e-12f);
+  x *= inv;
+  y *= inv;
+  z *= inv;
+}
+
+// F.cosine_similarity(eps=1e-5) of two (already normalised) rays
+__device__ __forceinline__ float cos_sim3(float ax, float ay, float az, float bx, float by, float bz) {
+  const float w12 = ax * bx + ay * by + az * bz;
+  const float n1 = fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-5f);
+  const float n2 = fmaxf(sqrtf(bx * bx + by * by + bz * bz), 1e-5f);
+  return w12 / (n1 * n2);
+}
+
+// nearest-neighbour source index of F.interpolate(mode="nearest"): floor(dst * in/out)
+__device__ __forceinline__ int nearest_src(int dst, int in_size, int out_size) {
+  const float scale = (float)in_size / (float)out_size;
+  return min((int)floorf((float)dst * scale), in_size - 1);
+}
+
+// hint MLP 3 -> 12 -> 12 -> 1, LeakyReLU(0.01) (modules/mesh_hint_volume.py:78-79,373-386)
+__device__ __forceinline__ float hint_mlp_eval(const float* __restrict__ hm, float s, float hint, float hw) {
+  // hm: V1[12x3], c1[12], V2[12x12], c2[12], V3[12], c3
+  const float* V1 = hm;
+  const float* c1 = hm + 36;
+  const float* V2 = hm + 48;
+  const float* c2 = hm + 192;
+  const float* V3 = hm + 204;
+  const float c3 = hm[216];
+  float a[12];
+#pragma unroll
+  for (int m = 0; m < 12; ++m) a[m] = lrelu(V1[m * 3 + 0] * s + V1[m * 3 + 1] * hint + V1[m * 3 + 2] * hw + c1[m], 0.01f);
+  float out = c3;
+#pragma unroll
+  for (int n = 0; n < 12; ++n) {
+    float acc = c2[n];
+#pragma unroll
+    for (int m = 0; m < 12; ++m) acc += V2[n * 12 + m] * a[m];
+    out += V3[n] * lrelu(acc, 0.01f);
+  }
+  return out;
+}
+
+
+}  // namespace dt

@@ -1,0 +1,412 @@
+// Fused plane-sweep + matching-MLP (+ hint-MLP) cost volume for gfx950, fp32 MFMA.
+//
+// Replaces (paths relative to /root/reference/src/doubletake/):
+//   FeatureVolumeManager.build_cost_volume            modules/feature_volume.py:81-356
+//   FeatureMeshHintVolumeManager.build_cost_volume    modules/mesh_hint_volume.py:84-393
+//   FastFeatureMeshHintVolumeManager.build_cost_volume modules/mesh_hint_volume.py:679-928
+// i.e. per (pixel, plane): backproject -> project into K source views -> bilinear warp ->
+// metadata -> MLP [Cin,128,128,1] (LeakyReLU 0.01) -> hint MLP [3,12,12,1].  The reference
+// materialises a [pairs, Cin] matrix (993 MB at 640x480/K7/D64 in the Fast variant); here the
+// input vector only ever exists as MFMA B-operands in registers.
+//
+// Mapping onto v_mfma_f32_32x32x2_f32 (D[i][j] += A[i][k] B[k][j], exact fp32):
+//   i = output feature (A = weights, read from LDS),  j = pixel (B = inputs, in registers),
+//   lane l = (pixel l&31, half l>>5); half h supplies k-slot h of every MFMA step.
+//   C/D layout: lane (p,h) holds features (r&3)+8*(r>>2)+4h of each 32-feature block, so the
+//   layer-1 accumulators are, after bias+LeakyReLU, exactly the B-operands layer 2 needs for
+//   the same lane: no transpose, no LDS round trip between the layers.
+//   The K order of each GEMM is a free permutation; the host packs the weights to match
+//   (doubletake_amd/modules/mlp_pack.py mirrors the step tables below).
+//
+// Work decomposition: a wave owns 32 consecutive pixels x PG planes.  The 16+3+3K+1 input
+// columns that do not depend on the plane (cur features, cur ray, pose metrics, bias) are
+// contracted once per task into `accp` and reused as the initial layer-1 accumulator of every
+// plane.  One 256-thread workgroup per CU keeps the plane-dependent layer-1 weights, layer-2
+// weights and the tail (b2, W3, b3) resident in LDS (152.6 KB for K=7).
+#include "common.hpp"
+#include "cv_geometry.hpp"
+
+namespace dt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kF = 16;             // matching feature channels
+constexpr int kStepsPerView = 12;  // 8 feature steps + 4 metadata steps
+constexpr int kPixFixed = 10;      // 8 cur-feature steps + (ray.x|ray.y) + (ray.z|bias)
+constexpr int kStepFloats = 256;   // [2 halves][32 lanes][4 blocks]
+constexpr int kW2Steps = 64;
+constexpr int kTailFloats = 260;   // b2r[128], w3r[128], b3, pad[3]
+constexpr int kMaxSrcMfma = 7;     // LDS budget: 12*K + 64 + ~1 KB <= 160 KB
+
+__host__ __device__ inline int mlp_w1dyn_floats(int K) { return K * kStepsPerView * kStepFloats; }
+__host__ __device__ inline int mlp_w1pix_floats(int K) { return (kPixFixed + 2 * K) * kStepFloats; }
+constexpr int kW2Floats = kW2Steps * kStepFloats;
+
+struct MlpArgs {
+  const float* cur;       // [b,16,h,w]
+  const float* src;       // [b,K,h,w,16]
+  const float* params;    // dt_cv_setup_f32 block
+  const float* w1dyn;     // packed
+  const float* w1pix;     // packed (read from global)
+  const float* w2p;       // packed
+  const float* tail;      // packed
+  const float* hint_mlp;  // 217 floats or null
+  const float* hint_d;    // [b,1,H2,W2]
+  const float* hint_w;
+  const float* hint_m;
+  float* vol;
+  int hint_h, hint_w2;
+  int out_nhwc;
+  int B, K, h, w, D;
+  int PG;                 // planes per task
+  int num_tiles, num_groups, num_tasks;
+};
+
+// one source view's gathered taps + metadata, produced by issue_view(), consumed later
+struct ViewData {
+  float4 t00a, t00b, t01a, t01b, t10a, t10b, t11a, t11b;  // this half's 8 channels of the 4 taps
+  float w00, w01, w10, w11;
+  float z, sx, sy, sz, ang;
+};
+
+__device__ __forceinline__ void issue_view(ViewData& v, const float* __restrict__ vp,
+                                           const float* __restrict__ src_view, float X, float Y, float Z,
+                                           float crx, float cry, float crz, int h, int w, float inv_w,
+                                           float inv_h, int half) {
+  const ViewProj q = project_view(vp, X, Y, Z);
+  const Taps t = bilinear_taps(q.u, q.v, h, w, inv_w, inv_h);
+  const float* p00 = src_view + ((size_t)t.y0 * w + t.x0) * kF + half * 8;
+  const float* p01 = src_view + ((size_t)t.y0 * w + t.x1) * kF + half * 8;
+  const float* p10 = src_view + ((size_t)t.y1 * w + t.x0) * kF + half * 8;
+  const float* p11 = src_view + ((size_t)t.y1 * w + t.x1) * kF + half * 8;
+  v.t00a = reinterpret_cast<const float4*>(p00)[0];
+  v.t00b = reinterpret_cast<const float4*>(p00)[1];
+  v.t01a = reinterpret_cast<const float4*>(p01)[0];
+  v.t01b = reinterpret_cast<const float4*>(p01)[1];
+  v.t10a = reinterpret_cast<const float4*>(p10)[0];
+  v.t10b = reinterpret_cast<const float4*>(p10)[1];
+  v.t11a = reinterpret_cast<const float4*>(p11)[0];
+  v.t11b = reinterpret_cast<const float4*>(p11)[1];
+  v.w00 = t.w00;
+  v.w01 = t.w01;
+  v.w10 = t.w10;
+  v.w11 = t.w11;
+  v.z = q.z;
+  float sx = X - vp[12], sy = Y - vp[13], sz = Z - vp[14];
+  normalize3(sx, sy, sz);
+  v.sx = sx;
+  v.sy = sy;
+  v.sz = sz;
+  v.ang = cos_sim3(crx, cry, crz, sx, sy, sz);
+}
+
+#define DT_MFMA4(ACC, A4, BVAL)                                                   \
+  do {                                                                            \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A4).x, (BVAL), ACC[0], 0, 0, 0); \
+    ACC[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A4).y, (BVAL), ACC[1], 0, 0, 0); \
+    ACC[2] = __builtin_amdgcn_mfma_f32_32x32x2f32((A4).z, (BVAL), ACC[2], 0, 0, 0); \
+    ACC[3] = __builtin_amdgcn_mfma_f32_32x32x2f32((A4).w, (BVAL), ACC[3], 0, 0, 0); \
+  } while (0)
+
+template <bool HINT>
+__global__ __launch_bounds__(256, 1) void cv_mlp_mfma_kernel(const MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int K = a.K, D = a.D, h = a.h, w = a.w;
+  const int n_dyn = mlp_w1dyn_floats(K);
+  float* lds_w1 = lds;
+  float* lds_w2 = lds + n_dyn;
+  float* lds_tail = lds_w2 + kW2Floats;
+
+  // ---- stage the weights once per workgroup ------------------------------------------------
+  {
+    const float4* g1 = reinterpret_cast<const float4*>(a.w1dyn);
+    float4* l1 = reinterpret_cast<float4*>(lds_w1);
+    for (int i = threadIdx.x; i < n_dyn / 4; i += 256) l1[i] = g1[i];
+    const float4* g2 = reinterpret_cast<const float4*>(a.w2p);
+    float4* l2 = reinterpret_cast<float4*>(lds_w2);
+    for (int i = threadIdx.x; i < kW2Floats / 4; i += 256) l2[i] = g2[i];
+    const float4* g3 = reinterpret_cast<const float4*>(a.tail);
+    float4* l3 = reinterpret_cast<float4*>(lds_tail);
+    for (int i = threadIdx.x; i < kTailFloats / 4; i += 256) l3[i] = g3[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, pl = lane & 31;
+  const size_t hw = (size_t)h * w;
+  const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
+  const int lane_off = (half * 32 + pl) * 4;  // float offset of this lane inside a step block
+  const int waves_total = gridDim.x * 4;
+  const float b3 = lds_tail[256];
+
+  for (int task = blockIdx.x * 4 + wave; task < a.num_tasks; task += waves_total) {
+    const int tile = task % a.num_tiles;
+    const int g = (task / a.num_tiles) % a.num_groups;
+    const int b = task / (a.num_tiles * a.num_groups);
+    const int d0 = g * a.PG, d1 = min(d0 + a.PG, D);
+    const float* p = a.params + (size_t)b * cv_params_floats(D, K);
+    const float* src_b = a.src + (size_t)b * K * hw * kF;
+
+    const size_t pixi = (size_t)tile * 32 + pl;
+    const bool live = pixi < hw;
+    const size_t pc = live ? pixi : hw - 1;
+    const int y = (int)(pc / w), x = (int)(pc % w);
+
+    // ---- per-pixel, plane-independent part ------------------------------------------------
+    float cur8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cur8[j] = a.cur[((size_t)b * kF + half * 8 + j) * hw + pc];
+    float rx, ry, rz;
+    pixel_ray(p + kCvInvK, x, y, rx, ry, rz);
+    float crx = rx, cry = ry, crz = rz;
+    normalize3(crx, cry, crz);
+
+    f32x16 accp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accp[i][r] = 0.f;
+    {
+      const float4* wp = reinterpret_cast<const float4*>(a.w1pix + lane_off);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float4 a4 = wp[s * (kStepFloats / 4)];
+        DT_MFMA4(accp, a4, cur8[s]);
+      }
+      {
+        const float4 a4 = wp[8 * (kStepFloats / 4)];
+        const float bv = half ? cry : crx;
+        DT_MFMA4(accp, a4, bv);
+      }
+      {
+        const float4 a4 = wp[9 * (kStepFloats / 4)];
+        const float bv = half ? 1.0f : crz;
+        DT_MFMA4(accp, a4, bv);
+      }
+      for (int k = 0; k < K; ++k) {
+        const float* vp = p + cv_view_off(D, k);
+        const float4 a4 = wp[(kPixFixed + 2 * k) * (kStepFloats / 4)];
+        const float bv = half ? vp[16] : vp[15];
+        DT_MFMA4(accp, a4, bv);
+        const float4 c4 = wp[(kPixFixed + 2 * k + 1) * (kStepFloats / 4)];
+        const float cv = half ? 0.0f : vp[17];
+        DT_MFMA4(accp, c4, cv);
+      }
+    }
+
+    // hint inputs of this pixel
+    bool hmask = false;
+    float hdepth = 0.f, hweight = 0.f;
+    if (HINT) {
+      const int sy = nearest_src(y, a.hint_h, h), sx = nearest_src(x, a.hint_w2, w);
+      const size_t hi = ((size_t)b * a.hint_h + sy) * a.hint_w2 + sx;
+      hmask = a.hint_m[hi] != 0.f;
+      hdepth = a.hint_d[hi];
+      hweight = hmask ? a.hint_w[hi] : 0.f;
+    }
+
+    // ---- planes -------------------------------------------------------------------------
+    ViewData nxt;
+    {
+      const float depth = p[kCvPlanes + d0];
+      issue_view(nxt, p + cv_view_off(D, 0), src_b, depth * rx, depth * ry, depth * rz, crx, cry, crz, h, w,
+                 inv_w, inv_h, half);
+    }
+    for (int d = d0; d < d1; ++d) {
+      const float depth = p[kCvPlanes + d];
+      const float X = depth * rx, Y = depth * ry, Z = depth * rz;
+      f32x16 acc1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc1[i] = accp[i];
+
+      for (int k = 0; k < K; ++k) {
+        const ViewData v = nxt;
+        // prefetch the next (plane, view) before this view's MFMA block
+        {
+          int nk = k + 1, nd = d;
+          if (nk == K) {
+            nk = 0;
+            nd = d + 1;
+          }
+          if (nd < d1) {
+            const float ndepth = p[kCvPlanes + nd];
+            issue_view(nxt, p + cv_view_off(D, nk), src_b + (size_t)nk * hw * kF, ndepth * rx, ndepth * ry,
+                       ndepth * rz, crx, cry, crz, h, w, inv_w, inv_h, half);
+          }
+        }
+        float f[8];
+        f[0] = v.t00a.x * v.w00 + v.t01a.x * v.w01 + v.t10a.x * v.w10 + v.t11a.x * v.w11;
+        f[1] = v.t00a.y * v.w00 + v.t01a.y * v.w01 + v.t10a.y * v.w10 + v.t11a.y * v.w11;
+        f[2] = v.t00a.z * v.w00 + v.t01a.z * v.w01 + v.t10a.z * v.w10 + v.t11a.z * v.w11;
+        f[3] = v.t00a.w * v.w00 + v.t01a.w * v.w01 + v.t10a.w * v.w10 + v.t11a.w * v.w11;
+        f[4] = v.t00b.x * v.w00 + v.t01b.x * v.w01 + v.t10b.x * v.w10 + v.t11b.x * v.w11;
+        f[5] = v.t00b.y * v.w00 + v.t01b.y * v.w01 + v.t10b.y * v.w10 + v.t11b.y * v.w11;
+        f[6] = v.t00b.z * v.w00 + v.t01b.z * v.w01 + v.t10b.z * v.w10 + v.t11b.z * v.w11;
+        f[7] = v.t00b.w * v.w00 + v.t01b.w * v.w01 + v.t10b.w * v.w10 + v.t11b.w * v.w11;
+        float dotp = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dotp += f[j] * cur8[j];
+        const float dot = dotp + __shfl_xor(dotp, 32, 64);
+        const float m = (v.z > 0.f) ? 1.f : 0.f;
+
+        const float4* wl = reinterpret_cast<const float4*>(lds_w1 + (size_t)k * kStepsPerView * kStepFloats + lane_off);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const float4 a4 = wl[s * (kStepFloats / 4)];
+          DT_MFMA4(acc1, a4, f[s]);
+        }
+        {
+          const float4 a4 = wl[8 * (kStepFloats / 4)];
+          const float bv = half ? v.z : m;
+          DT_MFMA4(acc1, a4, bv);
+        }
+        {
+          const float4 a4 = wl[9 * (kStepFloats / 4)];
+          const float bv = half ? v.ang : dot * m;
+          DT_MFMA4(acc1, a4, bv);
+        }
+        {
+          const float4 a4 = wl[10 * (kStepFloats / 4)];
+          const float bv = half ? v.sy : v.sx;
+          DT_MFMA4(acc1, a4, bv);
+        }
+        {
+          const float4 a4 = wl[11 * (kStepFloats / 4)];
+          const float bv = half ? ((k == 0) ? depth : 0.f) : v.sz;
+          DT_MFMA4(acc1, a4, bv);
+        }
+      }
+
+      // ---- layer 1 activation (bias came in through the constant-1 input) ------------------
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[i][r] = fmaxf(acc1[i][r], 0.01f * acc1[i][r]);
+
+      // ---- layer 2: acc2 = b2 + W2 h1 --------------------------------------------------------
+      f32x16 acc2[4];
+      {
+        const float* bl = lds_tail + half * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[i][r] = bl[i * 16 + r];
+      }
+      {
+        const float4* wl = reinterpret_cast<const float4*>(lds_w2 + lane_off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float4 a4 = wl[(i * 16 + r) * (kStepFloats / 4)];
+            DT_MFMA4(acc2, a4, acc1[i][r]);
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+      // ---- layer 3 + cross-half sum ---------------------------------------------------------
+      float s = 0.f;
+      {
+        const float* wl = lds_tail + 128 + half * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v2 = acc2[i][r];
+            s += wl[i * 16 + r] * fmaxf(v2, 0.01f * v2);
+          }
+      }
+      s += __shfl_xor(s, 32, 64);
+      s += b3;
+      if (HINT) {
+        const float hint = hmask ? fabsf(hdepth - depth) : -1.f;
+        s = hint_mlp_eval(a.hint_mlp, s, hint, hweight);
+      }
+      if (live && half == 0) {
+        if (a.out_nhwc)
+          a.vol[((size_t)b * hw + pixi) * D + d] = s;
+        else
+          a.vol[((size_t)b * D + d) * hw + pixi] = s;
+      }
+    }
+  }
+}
+
+
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus > 0) return g_num_cus;
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    n = 256;
+  }
+  g_num_cus = n;
+  return n;
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+extern "C" {
+
+int dt_cv_mlp_pack_floats(int num_src, int* w1dyn, int* w1pix, int* w2p, int* tail) {
+  DT_REQUIRE(num_src > 0 && num_src <= kMaxSrcMfma, "dt_cv_mlp_pack_floats: num_src=%d not in 1..%d", num_src, kMaxSrcMfma);
+  if (w1dyn) *w1dyn = mlp_w1dyn_floats(num_src);
+  if (w1pix) *w1pix = mlp_w1pix_floats(num_src);
+  if (w2p) *w2p = kW2Floats;
+  if (tail) *tail = kTailFloats;
+  return 0;
+}
+
+int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, const float* w1dyn,
+                       const float* w1pix, const float* w2p, const float* tail, const float* hint_mlp,
+                       const float* depth_hint, const float* hint_weights, const float* hint_mask, int hint_h,
+                       int hint_w, float* volume, int out_nhwc, int batch, int num_src, int h, int w,
+                       int num_planes, dt_stream_t s) {
+  DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0, "dt_cv_mlp_hint_f32: bad extents");
+  DT_REQUIRE(num_src > 0 && num_src <= kMaxSrcMfma, "dt_cv_mlp_hint_f32: num_src=%d not in 1..%d", num_src, kMaxSrcMfma);
+  DT_REQUIRE(cur && src && params && w1dyn && w1pix && w2p && tail && volume, "dt_cv_mlp_hint_f32: null pointer");
+  DT_REQUIRE(hint_mlp == nullptr || (depth_hint && hint_weights && hint_mask && hint_h > 0 && hint_w > 0),
+             "dt_cv_mlp_hint_f32: hint MLP given without hint maps");
+  MlpArgs a;
+  a.cur = cur; a.src = src; a.params = params; a.w1dyn = w1dyn; a.w1pix = w1pix; a.w2p = w2p; a.tail = tail;
+  a.hint_mlp = hint_mlp; a.hint_d = depth_hint; a.hint_w = hint_weights; a.hint_m = hint_mask;
+  a.vol = volume; a.hint_h = hint_h; a.hint_w2 = hint_w; a.out_nhwc = out_nhwc;
+  a.B = batch; a.K = num_src; a.h = h; a.w = w; a.D = num_planes;
+  const long hw = (long)h * w;
+  a.num_tiles = (int)((hw + 31) / 32);
+  const int cus = num_cus();
+  const long slots = (long)cus * 4;  // one wave per SIMD
+  // planes per task: minimise (rounds of tasks over the wave slots) x (MFMAs per task)
+  const long per_plane = (long)num_src * kStepsPerView * 4 + kW2Steps * 4;
+  const long per_task = (long)(kPixFixed + 2 * num_src) * 4;
+  int best_pg = num_planes;
+  long best_cost = -1;
+  for (int pg = 1; pg <= num_planes; ++pg) {
+    const long groups = (num_planes + pg - 1) / pg;
+    const long tasks = groups * a.num_tiles * batch;
+    const long rounds = (tasks + slots - 1) / slots;
+    const long cost = rounds * (per_task + (long)pg * per_plane);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_pg = pg; }
+  }
+  a.PG = best_pg;
+  a.num_groups = (num_planes + best_pg - 1) / best_pg;
+  a.num_tasks = a.num_groups * a.num_tiles * batch;
+  const int blocks = (int)((a.num_tasks + 3) / 4 < cus ? (a.num_tasks + 3) / 4 : cus);
+  const size_t lds_bytes = (size_t)(mlp_w1dyn_floats(num_src) + kW2Floats + kTailFloats) * sizeof(float);
+  hipError_t e;
+  if (hint_mlp) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cv_mlp_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail("dt_cv_mlp_hint_f32: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); }
+    hipLaunchKernelGGL(cv_mlp_mfma_kernel<true>, dim3(blocks), dim3(256), lds_bytes, to_stream(s), a);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cv_mlp_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail("dt_cv_mlp_hint_f32: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); }
+    hipLaunchKernelGGL(cv_mlp_mfma_kernel<false>, dim3(blocks), dim3(256), lds_bytes, to_stream(s), a);
+  }
+  return check_launch("dt_cv_mlp_hint_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,313 @@
+"""Drop-in plane-sweep cost-volume managers backed by the gfx950 HIP kernels.
+
+Same class names, constructor and forward signatures, return tuples and state-dict keys as the
+reference (paths relative to /root/reference/src/doubletake/):
+
+    CostVolumeManager                 modules/cost_volume.py:9-363
+    FeatureVolumeManager              modules/feature_volume.py:12-365  (+ Fast :368-796)
+    FeatureMeshHintVolumeManager      modules/mesh_hint_volume.py:12-449 (+ Fast :452-928)
+
+Plug point: ``model.cost_volume = <one of these>`` exactly as the reference swaps in its own
+fast path (utils/model_utils.py:30-35).  ``load_state_dict`` of a reference checkpoint's
+``cost_volume.*`` keys works unchanged.
+
+Differences kept on purpose (SURVEY.md "facts" 6): geometry is derived from the input shape on
+every call, so any (h, w) works, landscape or portrait; ``depth_planes_bdhw`` overrides are
+accepted only when every plane is constant over the image (the only way the reference uses
+them).
+
+There is no torch fallback: forward() raises if the tensors are not on a GPU or the HIP
+library cannot be loaded.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _abi
+from . import mlp_pack
+from .networks import MLP
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _require_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise _abi.DoubletakeHipError(
+            f"{name} is on {t.device}; the doubletake_amd cost volume only runs on a ROCm GPU (no CPU fallback)"
+        )
+
+
+class _Buffers(nn.Module):
+    """Holds the reference's geometry buffers so checkpoints load with strict=True."""
+
+    def __init__(self, **bufs):
+        super().__init__()
+        for k, v in bufs.items():
+            self.register_buffer(k, v)
+
+
+class CostVolumeManager(nn.Module):
+    """Dot-product plane-sweep volume (reference modules/cost_volume.py:9)."""
+
+    #: write the volume as torch.channels_last ([b,D,h,w] logical, NHWC physical); the conv
+    #: stack that consumes it (CVEncoder) is NHWC.  Only honoured by the MLP volumes.
+    channels_last_output = True
+
+    def __init__(self, matching_height, matching_width, num_depth_bins=64, matching_dim_size=None,
+                 num_source_views=None):
+        super().__init__()
+        self.num_depth_bins = num_depth_bins
+        self.matching_height = matching_height
+        self.matching_width = matching_width
+        self.initialise_for_projection()
+
+    # -- reference API ---------------------------------------------------------------------
+    def initialise_for_projection(self, device=None):
+        """Buffers with the reference's names/shapes (cost_volume.py:51-71,
+        geometry_utils.py:28-52,71-75).  The kernels do not read them."""
+        ramp = torch.linspace(0, 1, self.num_depth_bins).view(1, self.num_depth_bins, 1, 1)
+        self.register_buffer("linear_ramp_1d11", ramp)
+        h, w = self.matching_height, self.matching_width
+        xx, yy = torch.meshgrid(torch.arange(w), torch.arange(h), indexing="xy")
+        pix = torch.stack((xx, yy), 0) + 0.5
+        pix = torch.cat([pix, torch.ones_like(pix[:1])], 0).flatten(1).unsqueeze(0)
+        self.backprojector = _Buffers(pix_coords_13N=pix)
+        self.projector = _Buffers(eps=torch.tensor(1e-8).view(1, 1, 1))
+        if device is not None:
+            self.to(device)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # the pixel grid is shape dependent and unused here: never fail on a size mismatch
+        key = prefix + "backprojector.pix_coords_13N"
+        if key in state_dict and state_dict[key].shape != self.backprojector.pix_coords_13N.shape:
+            state_dict = dict(state_dict)
+            state_dict[key] = self.backprojector.pix_coords_13N
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def get_mask(self, pix_coords_bk2hw):
+        """cost_volume.py:73-94 (torch, for API parity; the kernels have their own)."""
+        u, v = pix_coords_bk2hw[:, :, 0], pix_coords_bk2hw[:, :, 1]
+        return (u > 2) & (u < self.matching_width - 2) & (v > 2) & (v < self.matching_height - 2)
+
+    def generate_depth_planes(self, batch_size, min_depth, max_depth):
+        """cost_volume.py:96-130; computed by dt_cv_setup_f32, returned as an expanded view."""
+        raise NotImplementedError("use forward(); planes are produced by dt_cv_setup_f32")
+
+    def indices_to_disparity(self, indices, depth_planes_bdhw):
+        return torch.gather(depth_planes_bdhw, 1, indices.unsqueeze(1)).squeeze(1)
+
+    # -- shared plumbing ---------------------------------------------------------------------
+    def _setup(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
+               depth_planes_bdhw):
+        _require_gpu(cur_feats, "cur_feats")
+        L = _abi.lib()
+        b, k, c, h, w = src_feats.shape
+        if cur_feats.shape != (b, c, h, w):
+            raise ValueError(f"cur_feats {tuple(cur_feats.shape)} does not match src_feats {tuple(src_feats.shape)}")
+        self.matching_height, self.matching_width = h, w
+        D = self.num_depth_bins
+        dev = cur_feats.device
+        stream = _abi.current_stream(dev)
+        cur = _f32c(cur_feats)
+        src = _f32c(src_feats)
+        Ks = _f32c(src_Ks).view(b, k, 4, 4)
+        ext = _f32c(src_extrinsics).view(b, k, 4, 4)
+        poses = _f32c(src_poses).view(b, k, 4, 4)
+        invK = _f32c(cur_invK).view(b, 4, 4)
+        mn = _f32c(min_depth.to(dev)).reshape(-1).expand(b).contiguous() if min_depth.numel() != b else _f32c(min_depth.to(dev)).reshape(b)
+        mx = _f32c(max_depth.to(dev)).reshape(-1).expand(b).contiguous() if max_depth.numel() != b else _f32c(max_depth.to(dev)).reshape(b)
+        pf = L.dt_cv_params_floats(D, k)
+        params = torch.empty(b, pf, device=dev, dtype=torch.float32)
+        _abi.check(L.dt_cv_setup_f32(_abi.ptr(Ks), _abi.ptr(ext), _abi.ptr(poses), _abi.ptr(invK), _abi.ptr(mn),
+                                     _abi.ptr(mx), b, k, D, _abi.ptr(params), stream), "dt_cv_setup_f32")
+        if depth_planes_bdhw is not None:
+            dp = depth_planes_bdhw
+            if dp.shape[0] != b or dp.shape[1] != D:
+                raise ValueError("depth_planes_bdhw must be [b, num_depth_bins, h, w]")
+            flat = dp.reshape(b, D, -1)
+            if not bool((flat == flat[:, :, :1]).all()):
+                raise NotImplementedError("per-pixel depth planes are not supported (the reference never uses them)")
+            params[:, 12:12 + D] = flat[:, :, 0].float()
+        src_nhwc = torch.empty(b, k, h, w, c, device=dev, dtype=torch.float32)
+        _abi.check(L.dt_nchw_to_nhwc_f32(_abi.ptr(src), _abi.ptr(src_nhwc), b * k, c, h, w, stream),
+                   "dt_nchw_to_nhwc_f32")
+        planes_bdhw = params[:, 12:12 + D].reshape(b, D, 1, 1).expand(b, D, h, w)
+        return L, stream, cur, src_nhwc, params, planes_bdhw, (b, k, c, h, w, D)
+
+    def _lowest(self, L, stream, vol, params, nhwc, dims):
+        b, k, c, h, w, D = dims
+        low = torch.empty(b, h, w, device=vol.device, dtype=torch.float32)
+        _abi.check(L.dt_cv_lowest_cost_f32(_abi.ptr(vol), _abi.ptr(params), _abi.ptr(low), int(nhwc), b, k, h, w, D,
+                                           stream), "dt_cv_lowest_cost_f32")
+        return low
+
+    def _mask(self, L, stream, params, per_view, dims):
+        b, k, c, h, w, D = dims
+        shape = (b, k, h, w) if per_view else (b, h, w)
+        m = torch.empty(shape, device=params.device, dtype=torch.uint8)
+        _abi.check(L.dt_cv_overall_mask_u8(_abi.ptr(params), _abi.ptr(m), int(per_view), b, k, h, w, D, stream),
+                   "dt_cv_overall_mask_u8")
+        return m.bool()
+
+    # -- forward -------------------------------------------------------------------------------
+    def build_cost_volume(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth,
+                          max_depth, depth_planes_bdhw=None, return_mask=False):
+        """cost_volume.py:219-315 -> (cost_volume_bdhw, depth_planes_bdhw, None)."""
+        vol, _, planes, _ = self.forward(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth,
+                                         max_depth, depth_planes_bdhw, return_mask)
+        return vol, planes, None
+
+    @torch.no_grad()
+    def forward(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
+                depth_planes_bdhw=None, return_mask=False):
+        """cost_volume.py:322-363 -> (cost_volume, lowest_cost, depth_planes_bdhw, None)."""
+        L, stream, cur, src_nhwc, params, planes, dims = self._setup(
+            cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth, depth_planes_bdhw)
+        b, k, c, h, w, D = dims
+        vol = torch.empty(b, D, h, w, device=cur.device, dtype=torch.float32)
+        _abi.check(L.dt_cv_dot_f32(_abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(vol), b, k, c, h, w, D,
+                                   stream), "dt_cv_dot_f32")
+        low = self._lowest(L, stream, vol, params, False, dims)
+        return vol, low, planes, None
+
+
+class FeatureVolumeManager(CostVolumeManager):
+    """Metadata-MLP volume (SimpleRecon; reference modules/feature_volume.py:12)."""
+
+    _has_hint = False
+    _fast_mask = True  # feature_volume.py:250-259: even the loop version returns any_k masks
+
+    def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=None, matching_dim_size=16,
+                 num_source_views=7):
+        super().__init__(matching_height, matching_width, num_depth_bins)
+        mlp_channels = list(mlp_channels) if mlp_channels is not None else [202, 128, 128, 1]
+        if matching_dim_size != 16:
+            raise NotImplementedError("matching_dim_size must be 16 (reference default, options.py:127-136)")
+        self.num_source_views = num_source_views
+        mlp_channels[0] = mlp_pack.Columns(num_source_views).total  # feature_volume.py:49-67
+        if mlp_channels[1:] != [128, 128, 1]:
+            raise NotImplementedError("the fused kernel implements the reference's [Cin,128,128,1] matching MLP")
+        self.mlp = MLP(channel_list=mlp_channels, disable_final_activation=True)
+        if self._has_hint:
+            self.hint_mlp = MLP(channel_list=[3, 12, 12, 1], disable_final_activation=True)
+        self._pack_cache = {}
+
+    # -- weights -----------------------------------------------------------------------------
+    def _mlp_arrays(self, mlp):
+        lin = [m for m in mlp.net if isinstance(m, nn.Linear)]
+        return [a for l in lin for a in (l.weight.detach(), l.bias.detach())]
+
+    def _packed(self, device):
+        params = list(self.mlp.parameters()) + (list(self.hint_mlp.parameters()) if self._has_hint else [])
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._pack_cache.get("key")
+        if hit == key:
+            return self._pack_cache["val"]
+        arrs = [a.float().cpu().numpy() for a in self._mlp_arrays(self.mlp)]
+        packed = mlp_pack.pack_mlp(*arrs, self.num_source_views)
+        val = {n: torch.from_numpy(v).to(device) for n, v in packed.items()}
+        raw = self._mlp_arrays(self.mlp)
+        val["raw"] = [_f32c(a.to(device)) for a in raw]
+        if self._has_hint:
+            h = [a.float().cpu().numpy() for a in self._mlp_arrays(self.hint_mlp)]
+            val["hint"] = torch.from_numpy(mlp_pack.pack_hint_mlp(*h)).to(device)
+        self._pack_cache = {"key": key, "val": val}
+        return val
+
+    # -- forward -------------------------------------------------------------------------------
+    def build_cost_volume(self, *args, **kwargs):
+        vol, _, planes, mask = self.forward(*args, **kwargs)
+        return vol, planes, mask
+
+    @torch.no_grad()
+    def forward(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
+                depth_planes_bdhw=None, return_mask=False):
+        """feature_volume.py forward -> (cost_volume, lowest_cost, depth_planes_bdhw, overall_mask_bhw)."""
+        return self._forward_impl(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth,
+                                  max_depth, None, depth_planes_bdhw, return_mask)
+
+    def _forward_impl(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
+                      cv_depth_hint_dict, depth_planes_bdhw, return_mask, _impl="mfma"):
+        L, stream, cur, src_nhwc, params, planes, dims = self._setup(
+            cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth, depth_planes_bdhw)
+        b, k, c, h, w, D = dims
+        if k != self.num_source_views:
+            raise ValueError(f"built for {self.num_source_views} source views, got {k}")
+        if c != 16:
+            raise ValueError("matching features must have 16 channels")
+        dev = cur.device
+        pk = self._packed(dev)
+        hint_ptr = hd = hw_ = hm = None
+        H2 = W2 = 0
+        if self._has_hint:
+            if cv_depth_hint_dict is None:
+                raise ValueError("cv_depth_hint_dict is required (depth_hint_b1hw, sampled_weights_b1hw, depth_hint_mask_b1hw)")
+            hd = _f32c(cv_depth_hint_dict["depth_hint_b1hw"].to(dev))
+            hw_ = _f32c(cv_depth_hint_dict["sampled_weights_b1hw"].to(dev))
+            hm = _f32c(cv_depth_hint_dict["depth_hint_mask_b1hw"].to(dev))
+            if not (hd.shape == hw_.shape == hm.shape) or hd.shape[0] != b or hd.shape[1] != 1:
+                raise ValueError("hint maps must all be [b,1,H,W]")
+            H2, W2 = hd.shape[-2:]
+            hint_ptr = pk["hint"]
+        nhwc = bool(self.channels_last_output) and _impl == "mfma"
+        if nhwc:
+            vol = torch.empty(b, D, h, w, device=dev, dtype=torch.float32, memory_format=torch.channels_last)
+        else:
+            vol = torch.empty(b, D, h, w, device=dev, dtype=torch.float32)
+        if _impl == "mfma":
+            _abi.check(L.dt_cv_mlp_hint_f32(
+                _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(pk["w1dyn"]), _abi.ptr(pk["w1pix"]),
+                _abi.ptr(pk["w2p"]), _abi.ptr(pk["tail"]), _abi.ptr(hint_ptr), _abi.ptr(hd), _abi.ptr(hw_),
+                _abi.ptr(hm), H2, W2, _abi.ptr(vol), int(nhwc), b, k, h, w, D, stream), "dt_cv_mlp_hint_f32")
+        elif _impl == "simple":
+            r = pk["raw"]
+            _abi.check(L.dt_cv_mlp_hint_simple_f32(
+                _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), *[_abi.ptr(t) for t in r], _abi.ptr(hint_ptr),
+                _abi.ptr(hd), _abi.ptr(hw_), _abi.ptr(hm), H2, W2, _abi.ptr(vol), b, k, h, w, D, stream),
+                "dt_cv_mlp_hint_simple_f32")
+        else:
+            raise ValueError(_impl)
+        low = self._lowest(L, stream, vol, params, nhwc, dims)
+        mask = None
+        if return_mask:
+            mask = self._mask(L, stream, params, per_view=not self._fast_mask, dims=dims)
+        return vol, low, planes, mask
+
+    def to_fast(self):
+        """Reference feature_volume.py:358-365.  The fused kernel *is* the fast path; the returned
+        manager shares the weights and differs only in the (reference-defined) mask semantics."""
+        fast_cls = FastFeatureMeshHintVolumeManager if self._has_hint else FastFeatureVolumeManager
+        m = fast_cls(self.matching_height, self.matching_width, num_depth_bins=self.num_depth_bins,
+                     num_source_views=self.num_source_views)
+        m.mlp = self.mlp
+        if self._has_hint:
+            m.hint_mlp = self.hint_mlp
+        return m.to(next(self.mlp.parameters()).device)
+
+
+class FastFeatureVolumeManager(FeatureVolumeManager):
+    _fast_mask = True
+
+
+class FeatureMeshHintVolumeManager(FeatureVolumeManager):
+    """DoubleTake's volume: matching MLP + mesh-hint MLP (reference modules/mesh_hint_volume.py:12)."""
+
+    _has_hint = True
+    _fast_mask = False  # mesh_hint_volume.py:270-287: per-view mask of the last plane
+
+    @torch.no_grad()
+    def forward(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
+                cv_depth_hint_dict, depth_planes_bdhw=None, return_mask=False):
+        """mesh_hint_volume.py:395-439 -> (cost_volume, lowest_cost, depth_planes_bdhw, overall_mask_bhw)."""
+        return self._forward_impl(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth,
+                                  max_depth, cv_depth_hint_dict, depth_planes_bdhw, return_mask)
+
+
+class FastFeatureMeshHintVolumeManager(FeatureMeshHintVolumeManager):
+    _fast_mask = True  # mesh_hint_volume.py:818-822

@@ -1,0 +1,196 @@
+/*
+ * doubletake_hip.h -- C ABI of the MI355X (gfx950) hot path for nianticlabs/doubletake.
+ *
+ * One shared library (doubletake_amd/_lib/libdoubletake_hip.so) exports everything below.
+ * Conventions:
+ *   - plain C linkage, raw DEVICE pointers + extents, no torch types;
+ *   - every entry point takes the HIP stream to launch on (dt_stream_t == hipStream_t);
+ *     nothing synchronises, nothing allocates device memory;
+ *   - return 0 on success, non-zero on failure; dt_last_error() gives the message
+ *     (thread-local).  Argument errors are detected before anything is launched.
+ *   - tensors are dense fp32 unless the name says otherwise; "bchw" = NCHW, "bhwc" = NHWC.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to
+ * /root/reference/src/doubletake/).  The reference has exactly one native ABI of its own
+ * (tools/marching_cubes/ext.cpp:4-6); everything else it runs through torch ops, so for
+ * those the "interface replaced" is the Python method whose body these kernels implement.
+ * INTEGRATION.md shows the reference-side binding for every entry point.
+ */
+#ifndef DOUBLETAKE_HIP_H
+#define DOUBLETAKE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dt_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------------ */
+int dt_version(void);
+const char* dt_last_error(void);
+/* number of HIP devices visible; <0 on runtime error.  No other call needs it. */
+int dt_device_count(void);
+
+/* ---- layout helpers (boundary between torch NCHW tensors and the kernels' NHWC) ------ */
+int dt_nchw_to_nhwc_f32(const float* src, float* dst, int n, int c, int h, int w, dt_stream_t s);
+int dt_nhwc_to_nchw_f32(const float* src, float* dst, int n, int c, int h, int w, dt_stream_t s);
+
+/* ---- plane-sweep cost volume ---------------------------------------------------------
+ * Parameter block written by dt_cv_setup_f32 and read by the volume kernels; per batch
+ * element: [0..8] invK[:3,:3] row-major, [9..11] pad, [12..12+D) depth planes, then per
+ * source view 20 floats: P = (K_src @ src_cam_T_cur_cam)[:3,:4] row-major (12),
+ * t_src = cur_cam_T_src_cam[:3,3] (3), pose_dist, R_measure, t_measure (3), pad (2).
+ */
+int dt_cv_params_floats(int num_planes, int num_src); /* floats per batch element */
+
+/* replaces: CostVolumeManager.generate_depth_planes (modules/cost_volume.py:96-130),
+ * Project3D's P = K @ cam_T_world (utils/geometry_utils.py:82), pose_distance
+ * (utils/geometry_utils.py:187-199). */
+int dt_cv_setup_f32(const float* src_Ks_bk44, const float* src_extrinsics_bk44,
+                    const float* src_poses_bk44, const float* cur_invK_b44,
+                    const float* min_depth_b, const float* max_depth_b,
+                    int batch, int num_src, int num_planes, float* params_out, dt_stream_t s);
+
+/* replaces: CostVolumeManager.build_cost_volume (modules/cost_volume.py:219-315)
+ * = warp_features (:132-217) + channel dot + z'>0 mask + sum over views.
+ * src_feats_bkhwc is NHWC (use dt_nchw_to_nhwc_f32 with n = b*k).  volume_bdhw is NCHW. */
+int dt_cv_dot_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc, const float* params,
+                  float* volume_bdhw, int batch, int num_src, int channels, int h, int w,
+                  int num_planes, dt_stream_t s);
+
+/* replaces: FeatureVolumeManager.build_cost_volume (modules/feature_volume.py:81-356) and
+ * FeatureMeshHintVolumeManager.build_cost_volume (modules/mesh_hint_volume.py:84-393; Fast
+ * variant :679-928): warp + metadata + 202->128->128->1 matching MLP (+ 3->12->12->1 hint
+ * MLP when hint_mlp != NULL), fused, fp32 MFMA.
+ *   w1dyn/w1pix/w2p/tail: matching-MLP weights re-packed for the kernel's K order by
+ *     doubletake_amd.modules.mlp_pack (sizes from dt_cv_mlp_pack_floats);
+ *   hint_mlp: 217 floats = V1[12x3], c1[12], V2[12x12], c2[12], V3[12], c3 (nn.Linear
+ *     layouts, row-major) or NULL;
+ *   depth_hint / hint_weights / hint_mask: [b,1,hint_h,hint_w] maps (NaN allowed where mask==0),
+ *     ignored when hint_mlp == NULL;
+ *   out_nhwc: 0 -> volume [b,D,h,w]; 1 -> [b,h,w,D] (torch channels_last of the same tensor).
+ */
+int dt_cv_mlp_pack_floats(int num_src, int* w1dyn, int* w1pix, int* w2p, int* tail);
+int dt_cv_mlp_hint_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc,
+                       const float* params, const float* w1dyn, const float* w1pix,
+                       const float* w2p, const float* tail, const float* hint_mlp,
+                       const float* depth_hint_b1HW, const float* hint_weights_b1HW,
+                       const float* hint_mask_b1HW, int hint_h, int hint_w, float* volume,
+                       int out_nhwc, int batch, int num_src, int h, int w, int num_planes,
+                       dt_stream_t s);
+
+/* Same function, one thread per (pixel, plane), plain fp32 FMAs, nn.Linear weight layouts
+ * (W1 [128,Cin], b1, W2 [128,128], b2, W3 [1,128], b3).  GPU-side cross-check used by the
+ * parity tests to localise failures; not used by the product modules. */
+int dt_cv_mlp_hint_simple_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc,
+                              const float* params, const float* W1, const float* b1,
+                              const float* W2, const float* b2, const float* W3,
+                              const float* b3, const float* hint_mlp,
+                              const float* depth_hint_b1HW, const float* hint_weights_b1HW,
+                              const float* hint_mask_b1HW, int hint_h, int hint_w,
+                              float* volume_bdhw, int batch, int num_src, int h, int w,
+                              int num_planes, dt_stream_t s);
+
+/* replaces: argmax + gather in CostVolumeManager.forward (modules/cost_volume.py:355-361).
+ * volume may be NCHW (nhwc = 0) or NHWC (nhwc = 1); first maximum wins. */
+int dt_cv_lowest_cost_f32(const float* volume, const float* params, float* lowest_bhw,
+                          int nhwc, int batch, int num_src, int h, int w, int num_planes,
+                          dt_stream_t s);
+
+/* replaces: get_mask + depth mask at the LAST plane (modules/cost_volume.py:73-94,
+ * modules/mesh_hint_volume.py:270-287 [per_view = 1 -> uint8 [b,k,h,w]] and :818-822
+ * [per_view = 0 -> uint8 [b,h,w]]). */
+int dt_cv_overall_mask_u8(const float* params, uint8_t* mask_out, int per_view, int batch,
+                          int num_src, int h, int w, int num_planes, dt_stream_t s);
+
+/* ---- conv stacks (cost-volume encoder / depth decoders) --------------------------------
+ * One implicit-GEMM primitive on NHWC fp32 tensors (fp32 MFMA):
+ *   out[n,y,x,co] = act( bias[co] + sum_{ky,kx,ci} W[co,ky,kx,ci] * in[n, y*stride+ky-pad,
+ *                   x*stride+kx-pad, ci] (+ residual[n,y,x,co]) )
+ * where `in` is the virtual channel-concatenation of up to two NHWC sources, each
+ * optionally nearest-upsampled x2 on the fly.  Replaces nn.Conv2d + bias + LeakyReLU/ELU +
+ * residual add + torch.cat + F.interpolate(nearest) as composed in BasicBlock
+ * (modules/layers.py:77-94), CVEncoder.forward (modules/networks.py:110-117),
+ * ConvBlock / ConvUpsampleAndConcatBlock (modules/networks_fast.py:17-40).
+ * Weights are pre-packed by doubletake_amd.modules.conv_pack (dt_conv_pack_floats).
+ */
+enum { DT_ACT_NONE = 0, DT_ACT_LRELU02 = 1, DT_ACT_ELU = 2 };
+
+typedef struct dt_conv_desc {
+  int n, h_out, w_out;      /* output extent */
+  int c_out;                /* multiple of 32 */
+  int ca, cb;               /* channels of source A / B (multiples of 8; cb may be 0) */
+  int up_a, up_b;           /* 1: source is (h_in/2, w_in/2) and read nearest-upsampled x2 */
+  int ksize;                /* 1 or 3 (pad = ksize/2) */
+  int stride;               /* 1 or 2 */
+  int act;                  /* DT_ACT_* */
+  int h_in, w_in;           /* extent of the (virtual, post-upsample) input */
+} dt_conv_desc;
+
+int64_t dt_conv_pack_floats(int c_out, int c_in, int ksize);
+/* W_oihw: nn.Conv2d weight [c_out, c_in, k, k] (device); packed: device buffer of
+ * dt_conv_pack_floats floats. */
+int dt_conv_pack_f32(const float* W_oihw, float* packed, int c_out, int c_in, int ksize,
+                     dt_stream_t s);
+int dt_conv2d_f32(const dt_conv_desc* d, const float* in_a, const float* in_b,
+                  const float* packed_w, const float* bias, const float* residual,
+                  float* out, dt_stream_t s);
+/* direct (one thread per output element) version of the same primitive taking the
+ * unpacked nn.Conv2d weight; GPU-side cross-check for the parity tests. */
+int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in_a, const float* in_b,
+                         const float* W_oihw, const float* bias, const float* residual,
+                         float* out, dt_stream_t s);
+/* 1x1 conv to ONE output channel (regression heads: modules/networks.py:60-63,
+ * modules/networks_fast.py:102-132 last layer).  in NHWC [n,h,w,c] -> out [n,h,w]. */
+int dt_conv1x1_head_f32(const float* in_nhwc, const float* w_c, const float* bias1,
+                        float* out, int64_t pixels, int c, dt_stream_t s);
+/* bilinear x2 upsample, align_corners=False (utils/generic_utils.py:95-104), NHWC. */
+int dt_upsample2x_bilinear_f32(const float* in_nhwc, float* out_nhwc, int n, int h, int w,
+                               int c, dt_stream_t s);
+/* exp() of the log-depth heads (experiment_modules/doubletake_model.py:410-418). */
+int dt_exp_f32(const float* in, float* out, int64_t count, dt_stream_t s);
+
+/* ---- TSDF fusion -----------------------------------------------------------------------
+ * Volume: values/weights fp16 [X,Y,Z] (Z fastest), voxel (i,j,k) centre =
+ * half(float(origin) + (i,j,k)*voxel_size) as in TSDF.generate_voxel_coords
+ * (tools/tsdf.py:157-166).  `active` is a bitmap of X*Y*Z bits (uint32 words) replacing
+ * the open3d HashSet of active voxel keys (tools/tsdf.py:79-84,530-538).
+ */
+/* replaces: TSDFFuser.integrate_depth for ONE frame (tools/tsdf.py:444-558) incl.
+ * get_frustum_bounds (:15-50) and project_to_camera (:401-412); fp16-faithful.
+ * frame_params: 48 floats prepared on the host by doubletake_amd.tools.tsdf
+ * (half-rounded K@T rows, frustum AABB, image size; see tsdf.hip). */
+int dt_tsdf_integrate_f16(uint16_t* values, uint16_t* weights, uint32_t* active,
+                          const float* origin3, float voxel_size, int X, int Y, int Z,
+                          const uint16_t* depth_hw_f16, int img_h, int img_w,
+                          const float* frame_params, float max_depth, float min_depth,
+                          int extended_neg_truncation, dt_stream_t s);
+/* replaces: TSDF.sample_tsdf (tools/tsdf.py:277-339), trilinear, align_corners=True, zeros
+ * padding.  fp16_math = 1 reproduces the reference's GPU branch (volume dtype half),
+ * 0 its CPU branch (fp32). */
+int dt_tsdf_sample_f16(const uint16_t* volume, const float* origin3, float voxel_size,
+                       int X, int Y, int Z, const float* points_n3, float* out_n,
+                       int64_t n, int fp16_math, dt_stream_t s);
+
+/* ---- marching cubes over the active-voxel set -------------------------------------------
+ * replaces: marching_cubes_(vol, isolevel, active_voxels, min_bounds, max_bounds)
+ * (tools/marching_cubes/ext.cpp:4-6, marching_cubes.h:47-69, marching_cubes.cu:455-597)
+ * with the CUDA path's semantics (active list, bounds, "corner < -0.99999 => skip").
+ * Two-phase: dt_mc_count writes per-cell vertex counts + exclusive scan and the total into
+ * counts_out[0] (cells) / counts_out[1] (vertices) on the DEVICE; the caller reads the two
+ * ints once, allocates, and calls dt_mc_generate.
+ */
+int64_t dt_mc_workspace_bytes(int X, int Y, int Z);
+int dt_mc_count(const uint16_t* values_f16, const uint32_t* active, int X, int Y, int Z,
+                float isolevel, const int* min_bounds3, const int* max_bounds3,
+                void* workspace, int* counts_out, dt_stream_t s);
+int dt_mc_generate(const uint16_t* values_f16, int X, int Y, int Z, float isolevel,
+                   const void* workspace, float* verts_v3, int64_t* faces_f3, int64_t* ids_v,
+                   int num_verts, dt_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOUBLETAKE_HIP_H */

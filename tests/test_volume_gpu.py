@@ -1,0 +1,155 @@
+"""GPU parity of the plane-sweep cost volume kernels (through the C ABI) against
+ (1) golden vectors captured from the reference, (2) the numpy oracle on seeded inputs,
+ (3) full-size (cfg1 / cfg2) checksums captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from doubletake_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["k2_land", "k7_land", "k7_b2", "k3_portrait", "k7_empty", "k2_ragged"]
+
+
+def _case(case):
+    import gpu_util as gu
+
+    g = load_golden(f"volume_{case}.npz")
+    b, k, h, w, D, seed, empty, behind = [int(v) for v in g["meta"]]
+    inp = syn.volume_inputs(b, k, h, w, 16, seed, empty_hint=bool(empty), behind_view=bool(behind))
+    return g, inp, gu.to_dev(inp), (b, k, h, w, D, seed)
+
+
+def _check_lowest(vol, low, planes_bd, atol):
+    """lowest_cost must be a plane whose cost is within atol of the per-pixel maximum."""
+    b, D = planes_bd.shape
+    vmax = vol.max(1)
+    idx = np.abs(planes_bd.reshape(b, D, 1, 1) - low[:, None]).argmin(1)
+    picked = np.take_along_axis(vol, idx[:, None], 1)[:, 0]
+    assert np.all(picked >= vmax - atol)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dot_volume_vs_reference_golden(case):
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import CostVolumeManager
+
+    g, inp, t, (b, k, h, w, D, seed) = _case(case)
+    m = CostVolumeManager(h, w, num_depth_bins=D).to(gu.dev())
+    vol, low, planes, mask = m(**gu.volume_call_args(t))
+    torch.cuda.synchronize()
+    assert mask is None and tuple(vol.shape) == (b, D, h, w) and tuple(planes.shape) == (b, D, h, w)
+    np.testing.assert_allclose(planes[:, :, 0, 0].cpu().numpy(), g["planes"], rtol=3e-6)
+    np.testing.assert_allclose(vol.cpu().numpy(), g["dot_volume"], atol=5e-4, rtol=0)
+    _check_lowest(g["dot_volume"], low.cpu().numpy(), g["planes"], 1e-3)
+
+
+@pytest.mark.parametrize("impl", ["simple", "mfma"])
+@pytest.mark.parametrize("case", CASES)
+def test_hint_volume_vs_reference_golden(case, impl):
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import FeatureMeshHintVolumeManager
+
+    g, inp, t, (b, k, h, w, D, seed) = _case(case)
+    m = FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 11 + seed)
+    gu.load_formula_mlp(m.hint_mlp, [3, 12, 12, 1], 77 + seed)
+    vol, low, planes, mask = m._forward_impl(**gu.volume_call_args(t), cv_depth_hint_dict=gu.hint_dict(t),
+                                             depth_planes_bdhw=None, return_mask=True, _impl=impl)
+    torch.cuda.synchronize()
+    v = vol.cpu().numpy()
+    err = np.abs(v - g["hint_volume"]).max()
+    assert err < 5e-5, f"{impl} max abs err {err}"
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["hint_mask_slow"])
+    _check_lowest(g["hint_volume"], low.cpu().numpy(), g["planes"], 1e-4)
+    # fast manager: same volume, any_k mask
+    f = m.to_fast()
+    vol2, _, _, mask2 = f(**gu.volume_call_args(t), cv_depth_hint_dict=gu.hint_dict(t), return_mask=True)
+    torch.cuda.synchronize()
+    assert np.abs(vol2.cpu().numpy() - g["hint_volume_fast"]).max() < 5e-5
+    np.testing.assert_array_equal(mask2.cpu().numpy(), g["hint_mask_fast"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_mlp_volume_no_hint_vs_reference_golden(case):
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import FeatureVolumeManager
+
+    g, inp, t, (b, k, h, w, D, seed) = _case(case)
+    m = FeatureVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 11 + seed)
+    vol, low, planes, mask = m(**gu.volume_call_args(t), return_mask=True)
+    torch.cuda.synchronize()
+    assert np.abs(vol.cpu().numpy() - g["mlp_volume"]).max() < 5e-5
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["mlp_mask_slow"])
+    np.testing.assert_array_equal(vol.contiguous().cpu().numpy(), vol.cpu().numpy())  # channels_last view is coherent
+
+
+def _probe_check(vol, prefix, g, atol):
+    flat = vol.reshape(-1)
+    idx = g[f"{prefix}_probe_idx"]
+    np.testing.assert_allclose(flat[idx], g[f"{prefix}_probe_val"], atol=atol, rtol=0)
+    assert abs(flat.astype(np.float64).sum() - g[f"{prefix}_sum"]) < atol * flat.size * 0.05 + 1e-2
+    assert abs(np.abs(flat.astype(np.float64)).sum() - g[f"{prefix}_abssum"]) < atol * flat.size * 0.05 + 1e-2
+
+
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2"])
+def test_fullsize_checksums_from_reference(cfg):
+    """BASELINE.json configs[0] (320x256, K2, D32) and configs[1] (640x480, K7, D64) volume shapes."""
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import CostVolumeManager, FeatureMeshHintVolumeManager
+
+    g = load_golden("volume_fullsize_checksums.npz")
+    b, k, h, w, D, seed = [int(v) for v in g[f"{cfg}_meta"]]
+    inp = syn.volume_inputs(b, k, h, w, 16, seed)
+    t = gu.to_dev(inp)
+    m = CostVolumeManager(h, w, num_depth_bins=D).to(gu.dev())
+    vol, _, _, _ = m(**gu.volume_call_args(t))
+    _probe_check(vol.cpu().numpy(), f"{cfg}_dot", g, 1e-3)
+    hm = FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    gu.load_formula_mlp(hm.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 11 + seed)
+    gu.load_formula_mlp(hm.hint_mlp, [3, 12, 12, 1], 77 + seed)
+    vol, _, _, _ = hm(**gu.volume_call_args(t), cv_depth_hint_dict=gu.hint_dict(t))
+    _probe_check(vol.contiguous().cpu().numpy(), f"{cfg}_hint", g, 1e-4)
+
+
+def test_cfg1_vs_oracle_full_tensor():
+    """Whole-tensor comparison with the numpy oracle at BASELINE configs[0] size."""
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import FeatureMeshHintVolumeManager
+    from oracle import cost_volume_ref as ref
+
+    b, k, h, w, D, seed = 1, 2, 64, 80, 32, 7
+    inp = syn.volume_inputs(b, k, h, w, 16, seed)
+    t = gu.to_dev(inp)
+    hm = FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    mw = gu.load_formula_mlp(hm.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 5)
+    hw_ = gu.load_formula_mlp(hm.hint_mlp, [3, 12, 12, 1], 6)
+    vol, low, _, _ = hm(**gu.volume_call_args(t), cv_depth_hint_dict=gu.hint_dict(t))
+    want, planes, _ = ref.feature_volume(
+        inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"], inp["cur_invK"],
+        inp["min_depth"], inp["max_depth"], D, mw, hint=gu.hint_dict(inp), hint_mlp_weights=hw_)
+    got = vol.cpu().numpy()
+    assert np.abs(got - want).max() < 5e-5
+    _check_lowest(want, low.cpu().numpy(), planes, 1e-4)
+
+
+def test_linearity_in_last_layer_at_full_size():
+    """Size-independent property at cfg2: scaling W3/b3 by c scales the (no-hint) volume by c."""
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import FeatureVolumeManager
+
+    b, k, h, w, D = 1, 7, 120, 160, 64
+    t = gu.to_dev(syn.volume_inputs(b, k, h, w, 16, 9))
+    m = FeatureVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 3)
+    v1 = m(**gu.volume_call_args(t))[0].clone()
+    with torch.no_grad():
+        m.mlp.net[4].weight.mul_(2.0)
+        m.mlp.net[4].bias.mul_(2.0)
+    v2 = m(**gu.volume_call_args(t))[0]
+    torch.cuda.synchronize()
+    assert torch.isfinite(v1).all()
+    assert (v2 - 2.0 * v1).abs().max().item() < 1e-5
