@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Headline benchmark: depth frames/sec of the DoubleTake hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): DoubleTake-small, 640x480 image, 7 source views, 64 depth
+planes, batch 1 per GPU.  One step = one keyframe through
+    mesh-hint cost volume (fused fp32-MFMA kernel) -> CVEncoder -> SkipDecoderRegression -> exp
+with every input (matching features, image-prior pyramid, poses, intrinsics, hint maps)
+already resident in HBM.  Synthetic closed-form inputs, formula-initialised weights of the real
+architecture.  With N > 1 every rank runs its own keyframe stream (keyframe-batch sharding) and
+the per-step "TSDF update" (predicted depth + K + pose of every rank) is exchanged with one RCCL
+all_gather and integrated into every rank's replica TSDF, inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (cv_mlp_mfma_kernel) timed live with HIP events on its stream
+  cpu_baseline -- the numpy oracle (oracle/, kind "port") on the same workload, rank 0, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+CFG = dict(image_h=480, image_w=640, num_src=7, planes=64, batch=1)
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def volume_flops(b, k, h, w, D):
+    """2 * pairs * (Cin*128 + 128*128 + 128 + 192), Cin = 20(K+1)+6K."""
+    cin = 20 * (k + 1) + 6 * k
+    return 2.0 * b * D * h * w * (cin * 128 + 128 * 128 + 128 + 192)
+
+
+def build_inputs(device, seed):
+    import torch
+    from doubletake_amd.utils import synthetic as syn
+
+    h, w = CFG["image_h"] // 4, CFG["image_w"] // 4
+    b, k = CFG["batch"], CFG["num_src"]
+    inp = syn.volume_inputs(b, k, h, w, 16, seed)
+    widths = [64, 64, 128, 256, 512]
+    pyr = syn.prior_pyramid(b, widths, 2 * h, 2 * w, seed + 50)
+    t = {n: torch.from_numpy(v).to(device) for n, v in inp.items()}
+    pyr_t = [torch.from_numpy(p).to(device).contiguous(memory_format=torch.channels_last) for p in pyr]
+    return inp, pyr, t, pyr_t
+
+
+def build_model(device):
+    import torch
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
+    from doubletake_amd.utils import synthetic as syn
+
+    m = DepthModelCVHint(CFG["image_h"], CFG["image_w"], image_encoder_name="resnet18d", depth_decoder_name="skip",
+                         matching_num_depth_bins=CFG["planes"], model_num_views=CFG["num_src"] + 1)
+    shapes = [tuple(p.shape) for _, p in m.named_parameters()]
+    arrs = syn.formula_params(shapes, 2024)
+    with torch.no_grad():
+        for (_, p), a in zip(m.named_parameters(), arrs):
+            p.copy_(torch.from_numpy(a))
+    return m.to(device)
+
+
+def cpu_baseline_frame(inp, pyr, model):
+    """One frame of the same workload through the numpy oracle.  Returns seconds."""
+    from oracle import cost_volume_ref as cref
+    from oracle import networks_ref as nref
+
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    lin = lambda pre: [(sd[f"{pre}.net.{i}.weight"], sd[f"{pre}.net.{i}.bias"]) for i in (0, 2, 4)]
+    hint = {n: inp[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
+    t0 = time.perf_counter()
+    vol, planes, _ = cref.feature_volume(
+        inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"], inp["cur_invK"],
+        inp["min_depth"], inp["max_depth"], CFG["planes"], lin("cost_volume.mlp"), hint=hint,
+        hint_mlp_weights=lin("cost_volume.hint_mlp"))
+    cref.lowest_cost(vol, planes)
+    cv = nref.cv_encoder(vol, pyr[1:], {k[len("cost_volume_net."):]: v for k, v in sd.items() if k.startswith("cost_volume_net.")})
+    out = nref.skip_decoder_regression([pyr[0]] + cv, {k[len("depth_decoder."):]: v for k, v in sd.items() if k.startswith("depth_decoder.")})
+    for k in list(out):
+        if k.startswith("log_depth"):
+            np.exp(out[k])
+    return time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="skip the TSDF integration of the gathered frames")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from doubletake_amd import _abi
+    from doubletake_amd.modules import cost_volume as cvmod
+    from doubletake_amd.parallel import KeyframeShardFuser
+
+    _abi.lib()
+    inp, pyr, t, pyr_t = build_inputs(device, seed=1000 + rank)
+    model = build_model(device)
+    hint = {n: t[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
+    fuser = None if args.no_fuse else KeyframeShardFuser(device, world, rank, CFG["image_h"], CFG["image_w"])
+
+    events = []
+
+    def hook(tag):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(device))
+        events.append((tag, ev))
+
+    def step(frame_idx):
+        out = model.forward_from_features(pyr_t, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"],
+                                          t["src_Ks"], t["cur_invK"], hint, return_mask=True)
+        if fuser is not None:
+            fuser.exchange_and_fuse(out["depth_pred_s0_b1hw"], frame_idx)
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    cvmod.FeatureVolumeManager._event_hook = None
+
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # dominant kernel: average launch duration from the HIP events recorded on its stream
+    begins = [e for tag, e in events if tag == "mlp_begin"]
+    ends = [e for tag, e in events if tag == "mlp_end"]
+    kern_ms = float(np.mean([b.elapsed_time(e) for b, e in zip(begins, ends)])) if begins else float("nan")
+
+    if rank == 0:
+        h, w = CFG["image_h"] // 4, CFG["image_w"] // 4
+        flops = volume_flops(CFG["batch"], CFG["num_src"], h, w, CFG["planes"])
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        frames = args.steps * CFG["batch"] * world
+        traffic = None
+        tf = os.path.join(REPO, "profiles", "roofline_traffic.json")
+        if os.path.isfile(tf):
+            try:
+                traffic = json.load(open(tf)).get("cv_mlp_mfma_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "depth frames/sec (640x480, 7 src views, 64 planes)",
+            "value": frames / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "DoubleTake-small hot path: mesh-hint cost volume + CVEncoder + SkipDecoderRegression, "
+                            "640x480, 7 source views, 64 planes, batch=1 per GPU (BASELINE.json configs[1])",
+                "matching_resolution": [h, w],
+                "frames_per_step_per_gpu": CFG["batch"],
+                "parallelism": f"keyframe-shard x{world}" + ("" if args.no_fuse else " + all_gather(depth,K,pose) + replica TSDF integrate"),
+            },
+            "roofline": {
+                "kernel": "cv_mlp_mfma_kernel (fused warp + metadata + matching MLP + hint MLP)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic,
+                "algorithmic_flops_per_launch": flops,
+                "avg_launch_ms": kern_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                from threadpoolctl import threadpool_info
+
+                nthreads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+            except Exception:
+                nthreads = 1
+            sec = cpu_baseline_frame(inp, pyr, model)
+            result["cpu_baseline"] = {
+                "value": 1.0 / sec,
+                "unit": "frames/s",
+                "cores": nthreads,
+                "kind": "port",
+                "sample": f"1 frame of the same workload through the numpy oracle (oracle/cost_volume_ref.py + "
+                          f"oracle/networks_ref.py), {sec:.1f} s; BLAS threads = cores, other numpy ops single-threaded",
+            }
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,8 +18,10 @@ class DoubletakeHipError(RuntimeError):
 
 
 class ConvDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in (
-        "n", "h_out", "w_out", "c_out", "ca", "cb", "up_a", "up_b", "ksize", "stride", "act", "h_in", "w_in")]
+    """struct dt_conv_desc (include/doubletake_hip.h)."""
+    _fields_ = [("n", C.c_int), ("h_out", C.c_int), ("w_out", C.c_int), ("c_out", C.c_int), ("nsrc", C.c_int),
+                ("c", C.c_int * 3), ("up", C.c_int * 3), ("ksize", C.c_int), ("stride", C.c_int), ("act", C.c_int),
+                ("h_in", C.c_int), ("w_in", C.c_int)]
 
 
 _P = C.c_void_p
@@ -42,6 +44,13 @@ SIGNATURES = {
     "dt_cv_mlp_hint_simple_f32": (_I, [_P] * 13 + [_I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "dt_cv_lowest_cost_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dt_cv_overall_mask_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dt_conv_pack_floats": (_L, [_I, _I, _I]),
+    "dt_conv_pack_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "dt_conv2d_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dt_conv2d_simple_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dt_conv1x1_head_f32": (_I, [_P, _P, _P, _P, _L, _I, _P]),
+    "dt_upsample2x_bilinear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dt_exp_f32": (_I, [_P, _P, _L, _P]),
 }
 
 

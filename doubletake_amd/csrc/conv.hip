@@ -1,0 +1,386 @@
+// Implicit-GEMM convolution for the cost-volume encoder / depth decoders, gfx950, fp32 MFMA.
+//
+// Replaces the torch ops composed in (paths relative to /root/reference/src/doubletake/):
+//   BasicBlock.forward            modules/layers.py:77-94   conv3x3+bias -> LeakyReLU(0.2) -> conv3x3+bias
+//                                                           (+identity | 1x1 | 3x3-s2 conv) -> LeakyReLU(0.2)
+//   CVEncoder.forward             modules/networks.py:110-117   (torch.cat with image-prior features)
+//   ConvBlock / ConvUpsampleAndConcatBlock  modules/networks_fast.py:17-40  (conv+ELU, nearest x2, cat)
+//   regression heads              modules/networks_fast.py:102-132, modules/networks.py:60-63
+//   upsample                      utils/generic_utils.py:95-104 (bilinear x2, align_corners=False)
+//
+// GEMM view: out[co][pixel] = sum_{tap,ci} W[co][tap][ci] * in[pixel+tap][ci]
+//   v_mfma_f32_32x32x2_f32 with i = output channel (A = packed weights, straight from L2),
+//   j = output pixel (B = input patch, staged per wave in LDS), lane = (pixel l&31, half l>>5).
+// A workgroup (4 waves) owns ONE 32-channel x (4x8)-pixel output block; the four waves split K
+// (8-channel input groups, round-robin) and reduce through LDS, so even the 15x20 level of the
+// encoder yields >= 4 waves per MFMA block and the grid stays fine-grained enough to balance
+// 1024 SIMDs.  Bias, residual add, LeakyReLU/ELU, channel concat of up to three sources and
+// nearest x2 upsampling of a source are fused (never materialised).
+#include "common.hpp"
+
+namespace dt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* src[3];
+  int c[3];
+  int up[3];
+  int nsrc;
+  const float* wp;
+  const float* bias;
+  const float* res;
+  float* out;
+  int n, h_out, w_out, c_out, h_in, w_in, act;
+  int groups;  // total 8-channel input groups over all sources
+  int tiles_x, tiles_y, co_blocks;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == DT_ACT_LRELU02) return v >= 0.f ? v : 0.2f * v;
+  if (act == DT_ACT_ELU) return v > 0.f ? v : expm1f(v);
+  return v;
+}
+
+constexpr int kPH = 4, kPW = 8;  // output patch of one MFMA pixel block
+
+template <int KS, int ST>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int IH = (kPH - 1) * ST + KS, IW = (kPW - 1) * ST + KS;
+  constexpr int NPIX = IH * IW;
+  constexpr int TILE_FLOATS = (NPIX * 8 > 1024) ? NPIX * 8 : 1024;
+  constexpr int PAD = KS / 2;
+  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, p = lane & 31;
+  const int py = p >> 3, px = p & 7;
+
+  int bid = blockIdx.x;
+  const int cb = bid % a.co_blocks;
+  bid /= a.co_blocks;
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int n = bid / a.tiles_y;
+
+  const int oy = ty * kPH + py, ox = tx * kPW + px;
+  const int iy0 = ty * kPH * ST - PAD, ix0 = tx * kPW * ST - PAD;
+  float* tile = lds + wave * TILE_FLOATS;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int taps = KS * KS;
+  const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
+
+  for (int g = wave; g < a.groups; g += 4) {
+    // locate the source of this 8-channel group
+    int s = 0, gl = g;
+    while (s + 1 < a.nsrc && gl >= (a.c[s] >> 3)) {
+      gl -= a.c[s] >> 3;
+      ++s;
+    }
+    const float* sp = a.src[s];
+    const int cs = a.c[s], up = a.up[s];
+    const int hs = up ? (a.h_in >> 1) : a.h_in, ws = up ? (a.w_in >> 1) : a.w_in;
+    // ---- stage the (IH x IW) x 8-channel input patch of this wave -------------------------
+    __builtin_amdgcn_wave_barrier();
+    for (int idx = lane >> 1; idx < NPIX; idx += 32) {
+      const int ly = idx / IW, lx = idx - ly * IW;
+      const int iy = iy0 + ly, ix = ix0 + lx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) {
+        const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
+        v = *reinterpret_cast<const float4*>(sp + (((size_t)n * hs + sy) * ws + sx) * cs + gl * 8 + (lane & 1) * 4);
+      }
+      *reinterpret_cast<float4*>(tile + idx * 8 + (lane & 1) * 4) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- taps -------------------------------------------------------------------------------
+    const float4* wg = wp4 + ((size_t)(cb * a.groups + g) * taps * 2 + half) * 32 + p;
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) {
+      const int ky = t / KS, kx = t - ky * KS;
+      const float4 a4 = wg[(size_t)t * 64];
+      const float4 b4 = *reinterpret_cast<const float4*>(tile + ((py * ST + ky) * IW + (px * ST + kx)) * 8 + half * 4);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+  }
+
+  // ---- cross-wave K reduction + fused epilogue ----------------------------------------------
+  __syncthreads();  // every wave is done reading its patch
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[r * 64 + lane] = acc[r];
+  __syncthreads();
+  float4 o;
+  {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wave * 4 + j;
+      v[j] = lds[0 * TILE_FLOATS + r * 64 + lane] + lds[1 * TILE_FLOATS + r * 64 + lane] +
+             lds[2 * TILE_FLOATS + r * 64 + lane] + lds[3 * TILE_FLOATS + r * 64 + lane];
+    }
+    o = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  if (oy < a.h_out && ox < a.w_out) {
+    const int co = cb * 32 + wave * 8 + half * 4;
+    const size_t off = (((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out + co;
+    if (a.bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+      o.x += bv.x;
+      o.y += bv.y;
+      o.z += bv.z;
+      o.w += bv.w;
+    }
+    if (a.res) {
+      const float4 rv = *reinterpret_cast<const float4*>(a.res + off);
+      o.x += rv.x;
+      o.y += rv.y;
+      o.z += rv.z;
+      o.w += rv.w;
+    }
+    o.x = apply_act(o.x, a.act);
+    o.y = apply_act(o.y, a.act);
+    o.z = apply_act(o.z, a.act);
+    o.w = apply_act(o.w, a.act);
+    *reinterpret_cast<float4*>(a.out + off) = o;
+  }
+}
+
+// ---- weight packing: OIHW -> [co_block][group][tap][half][32][4] -----------------------------
+__global__ void conv_pack_kernel(const float* __restrict__ W, float* __restrict__ packed, int c_out, int c_in, int ks) {
+  const int taps = ks * ks;
+  const int groups = c_in >> 3;
+  const size_t total = (size_t)c_out * c_in * taps;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t r = idx;
+    const int j = r & 3;
+    r >>= 2;
+    const int i = r & 31;
+    r >>= 5;
+    const int h = r & 1;
+    r >>= 1;
+    const int t = r % taps;
+    r /= taps;
+    const int g = r % groups;
+    const int cb = (int)(r / groups);
+    const int co = cb * 32 + i, ci = g * 8 + h * 4 + j;
+    packed[idx] = W[((size_t)co * c_in + ci) * taps + t];
+  }
+}
+
+// ---- direct conv (cross-check): one thread per output element --------------------------------
+__global__ void conv_simple_kernel(const ConvArgs a, const float* __restrict__ W, int ks, int st) {
+  const size_t total = (size_t)a.n * a.h_out * a.w_out * a.c_out;
+  const int pad = ks / 2;
+  int cin = 0;
+  for (int s = 0; s < a.nsrc; ++s) cin += a.c[s];
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t r = idx;
+    const int co = r % a.c_out;
+    r /= a.c_out;
+    const int ox = r % a.w_out;
+    r /= a.w_out;
+    const int oy = r % a.h_out;
+    const int n = (int)(r / a.h_out);
+    float acc = a.bias ? a.bias[co] : 0.f;
+    for (int ky = 0; ky < ks; ++ky)
+      for (int kx = 0; kx < ks; ++kx) {
+        const int iy = oy * st + ky - pad, ix = ox * st + kx - pad;
+        if (iy < 0 || iy >= a.h_in || ix < 0 || ix >= a.w_in) continue;
+        int cbase = 0;
+        for (int s = 0; s < a.nsrc; ++s) {
+          const int up = a.up[s];
+          const int hs = up ? (a.h_in >> 1) : a.h_in, ws = up ? (a.w_in >> 1) : a.w_in;
+          const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
+          const float* sp = a.src[s] + (((size_t)n * hs + sy) * ws + sx) * a.c[s];
+          for (int ci = 0; ci < a.c[s]; ++ci)
+            acc += W[(((size_t)co * cin + cbase + ci) * ks + ky) * ks + kx] * sp[ci];
+          cbase += a.c[s];
+        }
+      }
+    if (a.res) acc += a.res[idx];
+    a.out[idx] = apply_act(acc, a.act);
+  }
+}
+
+// ---- 1x1 conv to one channel: one wave per 64 pixels, lanes own pixels -----------------------
+__global__ __launch_bounds__(256) void conv1x1_head_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int64_t pixels, int c) {
+  // 4 lanes cooperate on one pixel (float4 strided over channels), shuffle-reduce
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t pix = t >> 2;
+  const int sub = (int)(t & 3);
+  float acc = 0.f;
+  if (pix < pixels) {
+    const float* ip = in + pix * c;
+    for (int ci = sub * 4; ci < c; ci += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(ip + ci);
+      const float4 ww = *reinterpret_cast<const float4*>(w + ci);
+      acc += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+    }
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  if (pix < pixels && sub == 0) out[pix] = acc + (bias ? bias[0] : 0.f);
+}
+
+// ---- bilinear x2 upsample (align_corners=False), NHWC, float4 over channels ------------------
+__global__ void upsample2x_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h, int w,
+                                           int c) {
+  const int c4 = c >> 2;
+  const size_t total = (size_t)n * (2 * h) * (2 * w) * c4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t r = idx;
+    const int cc = r % c4;
+    r /= c4;
+    const int ox = r % (2 * w);
+    r /= (2 * w);
+    const int oy = r % (2 * h);
+    const int b = (int)(r / (2 * h));
+    const float sy = fmaxf(((float)oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf(((float)ox + 0.5f) * 0.5f - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float4* base = reinterpret_cast<const float4*>(in) + (size_t)b * h * w * c4;
+    const float4 v00 = base[((size_t)y0 * w + x0) * c4 + cc], v01 = base[((size_t)y0 * w + x1) * c4 + cc];
+    const float4 v10 = base[((size_t)y1 * w + x0) * c4 + cc], v11 = base[((size_t)y1 * w + x1) * c4 + cc];
+    float4 o;
+    // same association as ATen's upsample_bilinear2d: hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
+    o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+    o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+    o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+    o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    reinterpret_cast<float4*>(out)[idx] = o;
+  }
+}
+
+static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* bias,
+                     const float* res, float* out, ConvArgs& a, const char* who) {
+  DT_REQUIRE(d != nullptr, "%s: null descriptor", who);
+  DT_REQUIRE(d->n > 0 && d->h_out > 0 && d->w_out > 0 && d->h_in > 0 && d->w_in > 0, "%s: bad extents", who);
+  DT_REQUIRE(d->nsrc >= 1 && d->nsrc <= 3, "%s: nsrc=%d not in 1..3", who, d->nsrc);
+  DT_REQUIRE(d->ksize == 1 || d->ksize == 3, "%s: ksize=%d (1 or 3)", who, d->ksize);
+  DT_REQUIRE(d->stride == 1 || d->stride == 2, "%s: stride=%d (1 or 2)", who, d->stride);
+  DT_REQUIRE(!(d->ksize == 1 && d->stride == 2), "%s: 1x1 stride-2 conv is not used by the reference", who);
+  DT_REQUIRE(d->act >= 0 && d->act <= 2, "%s: act=%d", who, d->act);
+  const int pad = d->ksize / 2;
+  DT_REQUIRE(d->h_out == (d->h_in + 2 * pad - d->ksize) / d->stride + 1 &&
+                 d->w_out == (d->w_in + 2 * pad - d->ksize) / d->stride + 1,
+             "%s: output extent %dx%d inconsistent with input %dx%d k=%d s=%d", who, d->h_out, d->w_out, d->h_in,
+             d->w_in, d->ksize, d->stride);
+  const float* ins[3] = {in0, in1, in2};
+  a.groups = 0;
+  for (int s = 0; s < 3; ++s) {
+    a.src[s] = nullptr;
+    a.c[s] = 0;
+    a.up[s] = 0;
+  }
+  for (int s = 0; s < d->nsrc; ++s) {
+    DT_REQUIRE(ins[s] != nullptr, "%s: source %d is null", who, s);
+    DT_REQUIRE(d->c[s] > 0 && d->c[s] % 8 == 0, "%s: source %d has %d channels (multiple of 8 required)", who, s, d->c[s]);
+    DT_REQUIRE(!d->up[s] || (d->h_in % 2 == 0 && d->w_in % 2 == 0), "%s: upsampled source needs even input extent", who);
+    a.src[s] = ins[s];
+    a.c[s] = d->c[s];
+    a.up[s] = d->up[s] ? 1 : 0;
+    a.groups += d->c[s] >> 3;
+  }
+  DT_REQUIRE(out != nullptr, "%s: null output", who);
+  a.nsrc = d->nsrc;
+  a.bias = bias;
+  a.res = res;
+  a.out = out;
+  a.n = d->n;
+  a.h_out = d->h_out;
+  a.w_out = d->w_out;
+  a.c_out = d->c_out;
+  a.h_in = d->h_in;
+  a.w_in = d->w_in;
+  a.act = d->act;
+  a.tiles_x = (d->w_out + kPW - 1) / kPW;
+  a.tiles_y = (d->h_out + kPH - 1) / kPH;
+  a.co_blocks = d->c_out / 32;
+  return 0;
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+extern "C" {
+
+int64_t dt_conv_pack_floats(int c_out, int c_in, int ksize) { return (int64_t)c_out * c_in * ksize * ksize; }
+
+int dt_conv_pack_f32(const float* W, float* packed, int c_out, int c_in, int ksize, dt_stream_t s) {
+  DT_REQUIRE(W && packed, "dt_conv_pack_f32: null pointer");
+  DT_REQUIRE(c_out > 0 && c_out % 32 == 0, "dt_conv_pack_f32: c_out=%d must be a multiple of 32", c_out);
+  DT_REQUIRE(c_in > 0 && c_in % 8 == 0, "dt_conv_pack_f32: c_in=%d must be a multiple of 8", c_in);
+  DT_REQUIRE(ksize == 1 || ksize == 3, "dt_conv_pack_f32: ksize=%d", ksize);
+  const size_t total = (size_t)c_out * c_in * ksize * ksize;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, to_stream(s), W, packed, c_out, c_in, ksize);
+  return check_launch("dt_conv_pack_f32");
+}
+
+int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* packed_w,
+                  const float* bias, const float* residual, float* out, dt_stream_t s) {
+  ConvArgs a;
+  if (int rc = fill_args(d, in0, in1, in2, bias, residual, out, a, "dt_conv2d_f32")) return rc;
+  DT_REQUIRE(packed_w != nullptr, "dt_conv2d_f32: null weights");
+  DT_REQUIRE(d->c_out > 0 && d->c_out % 32 == 0, "dt_conv2d_f32: c_out=%d must be a multiple of 32", d->c_out);
+  a.wp = packed_w;
+  const long blocks = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
+  DT_REQUIRE(blocks < 2147483647L, "dt_conv2d_f32: grid too large");
+  hipStream_t st = to_stream(s);
+  if (d->ksize == 3 && d->stride == 1)
+    hipLaunchKernelGGL((conv_mfma_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else if (d->ksize == 3 && d->stride == 2)
+    hipLaunchKernelGGL((conv_mfma_kernel<3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  return check_launch("dt_conv2d_f32");
+}
+
+int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* W,
+                         const float* bias, const float* residual, float* out, dt_stream_t s) {
+  ConvArgs a;
+  if (int rc = fill_args(d, in0, in1, in2, bias, residual, out, a, "dt_conv2d_simple_f32")) return rc;
+  DT_REQUIRE(W != nullptr, "dt_conv2d_simple_f32: null weights");
+  DT_REQUIRE(d->c_out > 0, "dt_conv2d_simple_f32: c_out=%d", d->c_out);
+  const size_t total = (size_t)a.n * a.h_out * a.w_out * a.c_out;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(conv_simple_kernel, dim3(blocks), dim3(256), 0, to_stream(s), a, W, d->ksize, d->stride);
+  return check_launch("dt_conv2d_simple_f32");
+}
+
+int dt_conv1x1_head_f32(const float* in, const float* w, const float* bias, float* out, int64_t pixels, int c,
+                        dt_stream_t s) {
+  DT_REQUIRE(in && w && out, "dt_conv1x1_head_f32: null pointer");
+  DT_REQUIRE(pixels > 0 && c > 0 && c % 4 == 0, "dt_conv1x1_head_f32: bad extents pixels=%ld c=%d", (long)pixels, c);
+  const int64_t threads = pixels * 4;
+  hipLaunchKernelGGL(conv1x1_head_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, to_stream(s), in, w, bias,
+                     out, pixels, c);
+  return check_launch("dt_conv1x1_head_f32");
+}
+
+int dt_upsample2x_bilinear_f32(const float* in, float* out, int n, int h, int w, int c, dt_stream_t s) {
+  DT_REQUIRE(in && out, "dt_upsample2x_bilinear_f32: null pointer");
+  DT_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "dt_upsample2x_bilinear_f32: bad extents");
+  const size_t total = (size_t)n * 4 * h * w * (c / 4);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(upsample2x_bilinear_kernel, dim3(blocks), dim3(256), 0, to_stream(s), in, out, n, h, w, c);
+  return check_launch("dt_upsample2x_bilinear_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""Hot-path half of the reference's ``DepthModelCVHint`` (experiment_modules/doubletake_model.py).
+
+The reference's forward (:265-425) is
+    image encoder (timm) -> matching encoder -> cost volume -> CVEncoder -> decoder -> exp
+The first two are ordinary PyTorch-ROCm conv stacks and stay outside this package (north star:
+"PyTorch-ROCm for the ordinary 2D conv stacks").  ``DepthModelCVHint`` here owns the three
+modules the HIP kernels replace, under the reference's attribute names so a reference
+checkpoint's ``cost_volume.* / cost_volume_net.* / depth_decoder.*`` keys load unchanged, and
+exposes ``forward_from_features`` = lines :341-349 and :375-423 of the reference forward.
+Encoders can be attached as ``self.encoder`` / ``self.matching_model`` (any nn.Module producing
+the reference's feature shapes) to run the whole ``forward``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ..modules import conv_ops as ops
+from ..modules.cost_volume import FeatureMeshHintVolumeManager
+from ..modules.networks import CVEncoder, DepthDecoderPP
+from ..modules.networks_fast import SkipDecoderRegression
+
+#: channel widths of the timm image encoders the reference uses (doubletake_model.py:121-130)
+ENCODER_WIDTHS = {"resnet18d": [64, 64, 128, 256, 512], "efficientnet": [24, 48, 64, 160, 256]}
+
+
+class DepthModelCVHint(nn.Module):
+    def __init__(self, image_height=384, image_width=512, image_encoder_name="resnet18d", depth_decoder_name="skip",
+                 matching_num_depth_bins=64, matching_scale=1, matching_feature_dims=16, model_num_views=8,
+                 min_matching_depth=0.25, max_matching_depth=5.0):
+        super().__init__()
+        key = "efficientnet" if "efficientnet" in image_encoder_name else "resnet18d"
+        self.num_ch_enc = list(ENCODER_WIDTHS[key])
+        self.matching_scale = matching_scale
+        self.min_matching_depth = min_matching_depth
+        self.max_matching_depth = max_matching_depth
+        self.cost_volume_net = CVEncoder(
+            num_ch_cv=matching_num_depth_bins, num_ch_enc=self.num_ch_enc[matching_scale:], num_ch_outs=[64, 128, 256, 384])
+        dec_in = self.num_ch_enc[:matching_scale] + self.cost_volume_net.num_ch_enc
+        if depth_decoder_name == "unet_pp":
+            self.depth_decoder = DepthDecoderPP(dec_in)
+        elif depth_decoder_name == "skip":
+            self.depth_decoder = SkipDecoderRegression(dec_in)
+        else:
+            raise ValueError("Unrecognized option for depth decoder name!")
+        self.cost_volume = FeatureMeshHintVolumeManager(
+            matching_height=image_height // (2 ** (matching_scale + 1)),
+            matching_width=image_width // (2 ** (matching_scale + 1)),
+            num_depth_bins=matching_num_depth_bins, matching_dim_size=matching_feature_dims,
+            num_source_views=model_num_views - 1)
+        self.encoder = None
+        self.matching_model = None
+
+    @torch.no_grad()
+    def forward_from_features(self, cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
+                              cur_cam_T_src_cam, src_K, cur_invK, cv_depth_hint_dict, return_mask=False):
+        """cur_feats: list of 5 image-prior maps (strides 2..32); matching feats at stride 4.
+        Returns the reference's output dict (doubletake_model.py:410-423)."""
+        dev = matching_cur_feats.device
+        min_depth = torch.tensor(self.min_matching_depth, device=dev, dtype=torch.float32).view(1, 1, 1, 1)
+        max_depth = torch.tensor(self.max_matching_depth, device=dev, dtype=torch.float32).view(1, 1, 1, 1)
+        cost_volume, lowest_cost, _, overall_mask = self.cost_volume(
+            cur_feats=matching_cur_feats, src_feats=matching_src_feats, src_extrinsics=src_cam_T_cur_cam,
+            src_poses=cur_cam_T_src_cam, src_Ks=src_K, cur_invK=cur_invK, min_depth=min_depth, max_depth=max_depth,
+            return_mask=return_mask, cv_depth_hint_dict=cv_depth_hint_dict)
+        cv_feats = self.cost_volume_net(cost_volume, cur_feats[self.matching_scale:])
+        feats = list(cur_feats[: self.matching_scale]) + cv_feats
+        depth_outputs = self.depth_decoder(feats)
+        for k in list(depth_outputs.keys()):
+            if not k.startswith("log_depth"):
+                continue
+            log_depth = depth_outputs[k].float()
+            depth_outputs[k] = log_depth
+            depth_outputs[k.replace("log_", "")] = ops.exp(log_depth)
+        depth_outputs["lowest_cost_bhw"] = lowest_cost
+        depth_outputs["overall_mask_bhw"] = overall_mask
+        return depth_outputs
+
+    @torch.no_grad()
+    def forward(self, phase, cur_data, src_data, unbatched_matching_encoder_forward=False, return_mask=False):
+        """Reference signature (doubletake_model.py:265).  Needs self.encoder / self.matching_model."""
+        if self.encoder is None or self.matching_model is None:
+            raise RuntimeError("attach .encoder and .matching_model (PyTorch-ROCm modules) or call forward_from_features")
+        s = self.matching_scale
+        src_K = src_data[f"K_s{s}_b44"]
+        cur_invK = cur_data[f"invK_s{s}_b44"]
+        src_cam_T_cur_cam = src_data["cam_T_world_b44"] @ cur_data["world_T_cam_b44"].unsqueeze(1)
+        cur_cam_T_src_cam = cur_data["cam_T_world_b44"].unsqueeze(1) @ src_data["world_T_cam_b44"]
+        cur_feats = self.encoder(cur_data["image_b3hw"])
+        b, k = src_data["image_b3hw"].shape[:2]
+        m_cur = self.matching_model(cur_data["image_b3hw"])
+        m_src = self.matching_model(src_data["image_b3hw"].flatten(0, 1))
+        m_src = m_src.view(b, k, *m_src.shape[1:])
+        return self.forward_from_features(cur_feats, m_cur, m_src, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K,
+                                          cur_invK, cur_data, return_mask=return_mask)

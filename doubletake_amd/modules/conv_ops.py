@@ -1,0 +1,168 @@
+"""Host-side plumbing for the NHWC fp32-MFMA conv primitive (csrc/conv.hip).
+
+Activations travel between our modules as torch tensors of logical shape [n,C,h,w] in
+``torch.channels_last`` memory format, i.e. physically NHWC -- still valid inputs for any
+torch op, so every module stays a drop-in at its own boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _abi
+
+ACT_NONE, ACT_LRELU02, ACT_ELU = 0, 1, 2
+
+
+def _require_gpu(t, name="input"):
+    if not t.is_cuda:
+        raise _abi.DoubletakeHipError(
+            f"{name} is on {t.device}; doubletake_amd convs only run on a ROCm GPU (no CPU fallback)")
+
+
+def empty_nhwc(n, c, h, w, device):
+    return torch.empty((n, c, h, w), device=device, dtype=torch.float32, memory_format=torch.channels_last)
+
+
+def _is_nhwc(x):
+    n, c, h, w = x.shape
+    return x.dtype == torch.float32 and x.stride() == (h * w * c, 1, w * c, c)
+
+
+def as_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Return x as a dense fp32 NHWC (channels_last) tensor, converting with our own kernel if needed."""
+    _require_gpu(x)
+    if x.dim() != 4:
+        raise ValueError(f"expected a 4-D tensor, got {tuple(x.shape)}")
+    if _is_nhwc(x):
+        return x
+    n, c, h, w = x.shape
+    src = x.float().contiguous()
+    out = empty_nhwc(n, c, h, w, x.device)
+    L = _abi.lib()
+    _abi.check(L.dt_nchw_to_nhwc_f32(_abi.ptr(src), _abi.ptr(out), n, c, h, w, _abi.current_stream(x.device)),
+               "dt_nchw_to_nhwc_f32")
+    return out
+
+
+def packed_weight(conv: nn.Conv2d, device):
+    """Device buffer with conv.weight re-packed for the MFMA kernel; cached per weight version."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(device))
+    hit = getattr(conv, "_dt_pack", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    co, ci, k, k2 = w.shape
+    if (k != k2 or conv.groups != 1 or conv.dilation != (1, 1) or conv.padding != (k // 2, k // 2)
+            or conv.padding_mode != "zeros"):
+        raise NotImplementedError(f"unsupported conv configuration {conv}")
+    L = _abi.lib()
+    wd = w.detach().to(device=device, dtype=torch.float32).contiguous()
+    packed = torch.empty(int(L.dt_conv_pack_floats(co, ci, k)), device=device, dtype=torch.float32)
+    _abi.check(L.dt_conv_pack_f32(_abi.ptr(wd), _abi.ptr(packed), co, ci, k, _abi.current_stream(device)),
+               "dt_conv_pack_f32")
+    conv._dt_pack = (key, packed)
+    return packed
+
+
+def _dev_param(conv, name, device):
+    """fp32 device copy of a small parameter (bias / head weight), cached per version."""
+    p = getattr(conv, name)
+    if p is None:
+        return None
+    if p.device == device and p.dtype == torch.float32 and p.is_contiguous():
+        return p.detach()
+    key = (p.data_ptr(), p._version, str(device))
+    cache = conv.__dict__.setdefault("_dt_small", {})
+    hit = cache.get(name)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    val = p.detach().to(device=device, dtype=torch.float32).contiguous()
+    cache[name] = (key, val)
+    return val
+
+
+def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
+    """Fused conv on NHWC tensors.
+
+    srcs: list of (tensor [n,c,h,w] channels_last, upsample_nearest_x2: bool), concatenated
+    along channels in order.  Returns a channels_last tensor [n, c_out, h_out, w_out].
+    """
+    L = _abi.lib()
+    x0, up0 = srcs[0]
+    dev = x0.device
+    n = x0.shape[0]
+    h_in = x0.shape[2] * (2 if up0 else 1)
+    w_in = x0.shape[3] * (2 if up0 else 1)
+    k = conv.kernel_size[0]
+    st = conv.stride[0]
+    co = conv.out_channels
+    d = _abi.ConvDesc()
+    d.n, d.c_out, d.nsrc, d.ksize, d.stride, d.act = n, co, len(srcs), k, st, act
+    d.h_in, d.w_in = h_in, w_in
+    pad = k // 2
+    d.h_out = (h_in + 2 * pad - k) // st + 1
+    d.w_out = (w_in + 2 * pad - k) // st + 1
+    ptrs = [None, None, None]
+    ctot = 0
+    for i, (t, up) in enumerate(srcs):
+        if not _is_nhwc(t):
+            raise ValueError("conv2d sources must be NHWC fp32 (use as_nhwc)")
+        hh, ww = t.shape[2] * (2 if up else 1), t.shape[3] * (2 if up else 1)
+        if (hh, ww) != (h_in, w_in) or t.shape[0] != n:
+            raise ValueError(f"source {i} extent {(hh, ww)} does not match {(h_in, w_in)}")
+        d.c[i] = t.shape[1]
+        d.up[i] = 1 if up else 0
+        ptrs[i] = _abi.ptr(t)
+        ctot += t.shape[1]
+    if ctot != conv.in_channels:
+        raise ValueError(f"conv expects {conv.in_channels} input channels, sources provide {ctot}")
+    out = empty_nhwc(n, co, d.h_out, d.w_out, dev)
+    bias = _dev_param(conv, "bias", dev)
+    if residual is not None and (not _is_nhwc(residual) or tuple(residual.shape) != tuple(out.shape)):
+        raise ValueError("residual must be NHWC with the output's shape")
+    stream = _abi.current_stream(dev)
+    if impl == "mfma":
+        wp = packed_weight(conv, dev)
+        _abi.check(L.dt_conv2d_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wp), _abi.ptr(bias),
+                                   _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_f32")
+    else:
+        wd = _dev_param(conv, "weight", dev)
+        _abi.check(L.dt_conv2d_simple_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wd), _abi.ptr(bias),
+                                          _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_simple_f32")
+    return out
+
+
+def conv1x1_head(x, conv: nn.Conv2d):
+    """1x1 conv to a single channel (regression head): NHWC [n,c,h,w] -> [n,1,h,w]."""
+    if conv.kernel_size != (1, 1) or conv.out_channels != 1:
+        raise NotImplementedError("head must be a 1x1 conv to one channel")
+    L = _abi.lib()
+    n, c, h, w = x.shape
+    dev = x.device
+    out = torch.empty((n, 1, h, w), device=dev, dtype=torch.float32)
+    wv = _dev_param(conv, "weight", dev)
+    b = _dev_param(conv, "bias", dev)
+    _abi.check(L.dt_conv1x1_head_f32(_abi.ptr(x), _abi.ptr(wv), _abi.ptr(b), _abi.ptr(out), n * h * w, c,
+                                     _abi.current_stream(dev)), "dt_conv1x1_head_f32")
+    return out
+
+
+def upsample2x_bilinear(x):
+    """utils/generic_utils.py:95-104 on an NHWC tensor."""
+    L = _abi.lib()
+    n, c, h, w = x.shape
+    out = empty_nhwc(n, c, 2 * h, 2 * w, x.device)
+    _abi.check(L.dt_upsample2x_bilinear_f32(_abi.ptr(x), _abi.ptr(out), n, h, w, c, _abi.current_stream(x.device)),
+               "dt_upsample2x_bilinear_f32")
+    return out
+
+
+def exp(x):
+    L = _abi.lib()
+    src = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty_like(src)
+    _abi.check(L.dt_exp_f32(_abi.ptr(src), _abi.ptr(out), src.numel(), _abi.current_stream(x.device)), "dt_exp_f32")
+    return out

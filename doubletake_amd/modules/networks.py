@@ -26,3 +26,127 @@ class MLP(nn.Module):
 
     def forward(self, x):
         return self.net(x)
+
+
+# --------------------------------------------------------------------------------------------
+# cost-volume encoder and UNet++ decoder
+# --------------------------------------------------------------------------------------------
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from . import conv_ops as ops  # noqa: E402
+from .layers import BasicBlock  # noqa: E402
+
+
+def double_basic_block(num_ch_in, num_ch_out, num_repeats=2):
+    """modules/networks.py:13-17 (children named '0', 'conv_0', ...)."""
+    layers = nn.Sequential(BasicBlock(num_ch_in, num_ch_out))
+    for i in range(num_repeats - 1):
+        layers.add_module(f"conv_{i}", BasicBlock(num_ch_out, num_ch_out))
+    return layers
+
+
+def _run_seq(seq, srcs, impl="mfma"):
+    x = None
+    for i, blk in enumerate(seq):
+        x = blk.run(srcs if i == 0 else [(x, False)], impl=impl)
+    return x
+
+
+class CVEncoder(nn.Module):
+    """Reference modules/networks.py:88-117: per level ds_conv_i (BasicBlock, stride 1|2) ->
+    cat(image-prior feature) -> two BasicBlocks.  The concat is never materialised: it is a
+    second source of the first conv of conv_i."""
+
+    def __init__(self, num_ch_cv, num_ch_enc, num_ch_outs):
+        super().__init__()
+        self.convs = nn.ModuleDict()
+        self.num_ch_enc = []
+        self.num_blocks = len(num_ch_outs)
+        for i in range(self.num_blocks):
+            num_ch_in = num_ch_cv if i == 0 else num_ch_outs[i - 1]
+            num_ch_out = num_ch_outs[i]
+            self.convs[f"ds_conv_{i}"] = BasicBlock(num_ch_in, num_ch_out, stride=1 if i == 0 else 2)
+            self.convs[f"conv_{i}"] = nn.Sequential(
+                BasicBlock(num_ch_enc[i] + num_ch_out, num_ch_out, stride=1),
+                BasicBlock(num_ch_out, num_ch_out, stride=1),
+            )
+            self.num_ch_enc.append(num_ch_out)
+
+    @torch.no_grad()
+    def forward(self, x, img_feats, _impl="mfma"):
+        x = ops.as_nhwc(x)
+        outputs = []
+        for i in range(self.num_blocks):
+            x = self.convs[f"ds_conv_{i}"].run([(x, False)], impl=_impl)
+            x = _run_seq(self.convs[f"conv_{i}"], [(x, False), (ops.as_nhwc(img_feats[i]), False)], impl=_impl)
+            outputs.append(x)
+        return outputs
+
+
+class _Head(nn.Sequential):
+    """output_i = Sequential(BasicBlock | Identity, Conv2d(c, 1, 1)) (modules/networks.py:60-63)."""
+
+    def run(self, x, impl="mfma"):
+        if isinstance(self[0], BasicBlock):
+            x = self[0].run([(x, False)], impl=impl)
+        return ops.conv1x1_head(x, self[1])
+
+
+class DepthDecoderPP(nn.Module):
+    """UNet++ decoder, reference modules/networks.py:20-85 (same ModuleDict keys).  The three-way
+    torch.cat feeding in_conv_ij is a 3-source conv; bilinear x2 upsampling is its own kernel."""
+
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
+        super().__init__()
+        if num_output_channels != 1:
+            raise NotImplementedError("regression heads have one output channel")
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        self.upsample_mode = "nearest"
+        self.scales = scales
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([64, 64, 128, 256])
+        self.convs = nn.ModuleDict()
+        for j in range(1, 5):
+            max_i = 4 - j
+            for i in range(max_i, -1, -1):
+                num_ch_out = int(self.num_ch_dec[i])
+                total = 0
+                num_ch_in = int(self.num_ch_enc[i + 1] if j == 1 else self.num_ch_dec[i + 1])
+                self.convs[f"diag_conv_{i + 1}{j - 1}"] = BasicBlock(num_ch_in, num_ch_out)
+                total += num_ch_out
+                num_ch_in = int(self.num_ch_enc[i] if j == 1 else self.num_ch_dec[i])
+                self.convs[f"right_conv_{i}{j - 1}"] = BasicBlock(num_ch_in, num_ch_out)
+                total += num_ch_out
+                if i + j != 4:
+                    num_ch_in = int(self.num_ch_dec[i + 1])
+                    self.convs[f"up_conv_{i + 1}{j}"] = BasicBlock(num_ch_in, num_ch_out)
+                    total += num_ch_out
+                self.convs[f"in_conv_{i}{j}"] = double_basic_block(total, num_ch_out)
+                self.convs[f"output_{i}"] = _Head(
+                    BasicBlock(num_ch_out, num_ch_out) if i != 0 else nn.Identity(),
+                    nn.Conv2d(num_ch_out, self.num_output_channels, 1),
+                )
+
+    @torch.no_grad()
+    def forward(self, input_features, _impl="mfma"):
+        prev = [ops.as_nhwc(f) for f in input_features]
+        outputs = []
+        pending = {}
+        for j in range(1, 5):
+            for i in range(4 - j, -1, -1):
+                srcs = [(self.convs[f"right_conv_{i}{j - 1}"].run([(prev[i], False)], impl=_impl), False)]
+                d = self.convs[f"diag_conv_{i + 1}{j - 1}"].run([(prev[i + 1], False)], impl=_impl)
+                srcs.append((ops.upsample2x_bilinear(d), False))
+                if i + j != 4:
+                    u = self.convs[f"up_conv_{i + 1}{j}"].run([(outputs[-1], False)], impl=_impl)
+                    srcs.append((ops.upsample2x_bilinear(u), False))
+                out = _run_seq(self.convs[f"in_conv_{i}{j}"], srcs, impl=_impl)
+                outputs.append(out)
+                # the reference evaluates output_i for every j and keeps the last (networks.py:83);
+                # only the surviving evaluation is computed here.
+                pending[i] = out
+            prev = outputs[::-1]
+        return {f"log_depth_pred_s{i}_b1hw": self.convs[f"output_{i}"].run(pending[i], impl=_impl)
+                for i in sorted(pending, reverse=True)}

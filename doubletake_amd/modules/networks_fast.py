@@ -1,0 +1,89 @@
+"""DoubleTake-small depth decoder (reference modules/networks_fast.py:6-141) on the fused HIP
+conv primitive: conv3x3+bias+ELU pairs, nearest x2 upsample and skip concat folded into the
+consumer conv's input gather, 1x1 regression heads."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import conv_ops as ops
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, in_ch, out_ch, use_elu=True, use_bn=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_ch, out_ch, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv2d(out_ch, out_ch, kernel_size=3, padding=1)
+        if not use_elu:
+            raise NotImplementedError("the reference always uses ELU here")
+        self.non_lin = nn.ELU(inplace=True)
+
+    def run(self, srcs, impl="mfma"):
+        x = ops.conv2d(srcs, self.conv1, act=ops.ACT_ELU, impl=impl)
+        return ops.conv2d([(x, False)], self.conv2, act=ops.ACT_ELU, impl=impl)
+
+    @torch.no_grad()
+    def forward(self, x):
+        return self.run([(ops.as_nhwc(x), False)])
+
+
+class ConvUpsampleAndConcatBlock(nn.Module):
+    def __init__(self, in_ch, out_ch, skip_chns, use_elu=True, use_bn=False):
+        super().__init__()
+        self.pre_concat_conv = ConvBlock(in_ch, out_ch, use_elu=use_elu, use_bn=use_bn)
+        self.post_concat_conv = ConvBlock(out_ch + skip_chns, out_ch, use_elu=use_elu, use_bn=use_bn)
+
+    def run(self, x, cat_feats, impl="mfma"):
+        x = self.pre_concat_conv.run([(x, False)], impl=impl)
+        # nearest x2 + cat are index transforms inside the next conv's gather
+        return self.post_concat_conv.run([(x, True), (cat_feats, False)], impl=impl)
+
+    @torch.no_grad()
+    def forward(self, x, cat_feats):
+        return self.run(ops.as_nhwc(x), ops.as_nhwc(cat_feats))
+
+
+class SkipDecoder(nn.Module):
+    def __init__(self, input_channels, use_bn=False):
+        super().__init__()
+        input_channels = list(input_channels)[::-1]
+        self.input_channels = input_channels
+        self.output_channels = [256, 128, 64, 64]
+        self.num_ch_dec = self.output_channels[::-1]
+        for bi in range(4):
+            setattr(self, f"block{bi + 1}", ConvUpsampleAndConcatBlock(
+                in_ch=input_channels[bi], out_ch=self.output_channels[bi], skip_chns=input_channels[bi + 1],
+                use_bn=use_bn))
+
+    def _features(self, features, impl="mfma"):
+        feats = [ops.as_nhwc(f) for f in features]
+        out = {}
+        x = feats[-1]
+        for bi, scale in ((1, 3), (2, 2), (3, 1), (4, 0)):
+            x = getattr(self, f"block{bi}").run(x, feats[-1 - bi], impl=impl)
+            out[f"feature_s{scale}_b1hw"] = x
+        return out
+
+    @torch.no_grad()
+    def forward(self, features):
+        return self._features(features)
+
+
+class SkipDecoderRegression(SkipDecoder):
+    def __init__(self, input_channels, use_bn=False):
+        super().__init__(input_channels, use_bn=use_bn)
+        for oi in range(4):
+            setattr(self, f"out{oi + 1}", nn.Sequential(
+                nn.Conv2d(self.output_channels[oi], 128, kernel_size=1), nn.ELU(inplace=True),
+                nn.Conv2d(128, 128, kernel_size=1), nn.ELU(inplace=True),
+                nn.Conv2d(128, 1, kernel_size=1)))
+
+    @torch.no_grad()
+    def forward(self, features, _impl="mfma"):
+        out = self._features(features, impl=_impl)
+        for oi, scale in ((1, 3), (2, 2), (3, 1), (4, 0)):
+            head = getattr(self, f"out{oi}")
+            y = ops.conv2d([(out[f"feature_s{scale}_b1hw"], False)], head[0], act=ops.ACT_ELU, impl=_impl)
+            y = ops.conv2d([(y, False)], head[2], act=ops.ACT_ELU, impl=_impl)
+            out[f"log_depth_pred_s{scale}_b1hw"] = ops.conv1x1_head(y, head[4])
+        return out

@@ -109,7 +109,7 @@ int dt_cv_overall_mask_u8(const float* params, uint8_t* mask_out, int per_view, 
  * One implicit-GEMM primitive on NHWC fp32 tensors (fp32 MFMA):
  *   out[n,y,x,co] = act( bias[co] + sum_{ky,kx,ci} W[co,ky,kx,ci] * in[n, y*stride+ky-pad,
  *                   x*stride+kx-pad, ci] (+ residual[n,y,x,co]) )
- * where `in` is the virtual channel-concatenation of up to two NHWC sources, each
+ * where `in` is the virtual channel-concatenation of up to three NHWC sources, each
  * optionally nearest-upsampled x2 on the fly.  Replaces nn.Conv2d + bias + LeakyReLU/ELU +
  * residual add + torch.cat + F.interpolate(nearest) as composed in BasicBlock
  * (modules/layers.py:77-94), CVEncoder.forward (modules/networks.py:110-117),
@@ -121,8 +121,9 @@ enum { DT_ACT_NONE = 0, DT_ACT_LRELU02 = 1, DT_ACT_ELU = 2 };
 typedef struct dt_conv_desc {
   int n, h_out, w_out;      /* output extent */
   int c_out;                /* multiple of 32 */
-  int ca, cb;               /* channels of source A / B (multiples of 8; cb may be 0) */
-  int up_a, up_b;           /* 1: source is (h_in/2, w_in/2) and read nearest-upsampled x2 */
+  int nsrc;                 /* 1..3 sources, concatenated along channels in order */
+  int c[3];                 /* channels of each source (multiples of 8) */
+  int up[3];                /* 1: source is (h_in/2, w_in/2) and read nearest-upsampled x2 */
   int ksize;                /* 1 or 3 (pad = ksize/2) */
   int stride;               /* 1 or 2 */
   int act;                  /* DT_ACT_* */
@@ -134,14 +135,14 @@ int64_t dt_conv_pack_floats(int c_out, int c_in, int ksize);
  * dt_conv_pack_floats floats. */
 int dt_conv_pack_f32(const float* W_oihw, float* packed, int c_out, int c_in, int ksize,
                      dt_stream_t s);
-int dt_conv2d_f32(const dt_conv_desc* d, const float* in_a, const float* in_b,
+int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2,
                   const float* packed_w, const float* bias, const float* residual,
                   float* out, dt_stream_t s);
 /* direct (one thread per output element) version of the same primitive taking the
  * unpacked nn.Conv2d weight; GPU-side cross-check for the parity tests. */
-int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in_a, const float* in_b,
-                         const float* W_oihw, const float* bias, const float* residual,
-                         float* out, dt_stream_t s);
+int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in0, const float* in1,
+                         const float* in2, const float* W_oihw, const float* bias,
+                         const float* residual, float* out, dt_stream_t s);
 /* 1x1 conv to ONE output channel (regression heads: modules/networks.py:60-63,
  * modules/networks_fast.py:102-132 last layer).  in NHWC [n,h,w,c] -> out [n,h,w]. */
 int dt_conv1x1_head_f32(const float* in_nhwc, const float* w_c, const float* bias1,
