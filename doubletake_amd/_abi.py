@@ -24,6 +24,11 @@ class ConvDesc(C.Structure):
                 ("h_in", C.c_int), ("w_in", C.c_int)]
 
 
+class TsdfThresholds(C.Structure):
+    """struct dt_tsdf_thresholds (include/doubletake_hip.h)."""
+    _fields_ = [(n, C.c_float) for n in ("trunc", "thr_neg", "thr_pos", "max_depth_h", "min_depth", "depth_range")]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -51,6 +56,14 @@ SIGNATURES = {
     "dt_conv1x1_head_f32": (_I, [_P, _P, _P, _P, _L, _I, _P]),
     "dt_upsample2x_bilinear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dt_exp_f32": (_I, [_P, _P, _L, _P]),
+    "dt_tsdf_frame_params_floats": (_I, []),
+    "dt_tsdf_frame_setup_f16": (_I, [_P, _P, _I, _I, _F, _F, _P, _P]),
+    "dt_tsdf_integrate_f16": (_I, [_P, _P, _P, C.POINTER(_F), _F, _I, _I, _I, _P, _I, _I, _P,
+                                   C.POINTER(TsdfThresholds), _P]),
+    "dt_tsdf_sample_f16": (_I, [_P, C.POINTER(_F), _F, _I, _I, _I, _P, _P, _L, _I, _P]),
+    "dt_mc_workspace_bytes": (_L, [_I, _I, _I]),
+    "dt_mc_count": (_I, [_P, _P, _I, _I, _I, _F, C.POINTER(_I), C.POINTER(_I), _P, _P, _P]),
+    "dt_mc_generate": (_I, [_P, _P, _I, _I, _I, _F, C.POINTER(_I), C.POINTER(_I), _P, _P, _P, _P, _I, _P]),
 }
 
 

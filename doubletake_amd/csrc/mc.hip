@@ -1,0 +1,264 @@
+// Marching cubes over the TSDF's active-voxel bitmap, gfx950.
+//
+// Replaces the reference's only native code (paths relative to /root/reference/src/doubletake/):
+//   tools/marching_cubes/marching_cubes.cu:164-250  ClassifyVoxelKernel
+//   tools/marching_cubes/marching_cubes.cu:263-278  CompactVoxelsKernel (+ two thrust scans)
+//   tools/marching_cubes/marching_cubes.cu:294-424  GenerateFacesKernel
+//   tools/marching_cubes/marching_cubes.cu:455-597  MarchingCubesCuda (host)
+// keeping the CUDA path's semantics: only cells whose base voxel is in the active set, inside
+// [min_bounds, max_bounds) and inside the volume; a cell with any corner < -0.99999 (unobserved)
+// is skipped; case index bit vi set when value(vi) < isolevel; vertex interpolation snaps to an
+// endpoint when |iso - v| < 1e-5 or |v1 - v2| < 1e-5; edge id = v1*(W + W*H + W*H*D) + v2.
+//
+// Differences by design: the active set is a bitmap in voxel-id order instead of
+// an open3d HashSet list, so output order is deterministic (ascending voxel id); the cell count
+// comes from the occupancy flags (the reference's voxelVerts[N-1]/voxelOccupied[N-1] mix-up is not
+// reproduced); the half volume is read directly (the reference first materialises a float copy);
+// one host read of two ints instead of four .item() syncs + two device synchronisations.
+//
+// Two phases over the same thread->voxel mapping (256 consecutive voxel ids per block):
+//   count:    per-block vertex totals -> single-block exclusive scan -> total in counts_out
+//   generate: recompute the per-thread count, block-local scan in LDS, write vertices / faces / ids
+#include "common.hpp"
+#include "mc_tables.hpp"
+
+namespace dt {
+
+typedef _Float16 half_t;
+
+__device__ __forceinline__ float ldh(const uint16_t* p, size_t i) {
+  half_t h;
+  const uint16_t b = p[i];
+  __builtin_memcpy(&h, &b, 2);
+  return (float)h;
+}
+
+struct McArgs {
+  const uint16_t* vol;
+  const uint32_t* active;
+  int X, Y, Z;
+  float iso;
+  int mn[3], mx[3];
+};
+
+// corner code c = dx + 2*dy + 4*dz (dx along Z/k, dy along Y/j, dz along X/i) -> Bourke corner vi
+__device__ __constant__ const unsigned char kCodeToVi[8] = {0, 1, 4, 5, 3, 2, 7, 6};
+// Bourke edge -> its two corner codes, always low -> high coordinate
+__device__ __constant__ const unsigned char kEdgeCodes[12][2] = {{0, 1}, {1, 5}, {4, 5}, {0, 4}, {2, 3}, {3, 7},
+                                                                {6, 7}, {2, 6}, {0, 2}, {1, 3}, {5, 7}, {4, 6}};
+
+// returns the number of vertices the cell at voxel id emits (0 if inactive / out of bounds /
+// unobserved); fills case index and corner values when non-zero
+__device__ __forceinline__ int classify(const McArgs& a, size_t id, int& i, int& j, int& k, int& cubeindex,
+                                        float val[8]) {
+  const size_t total = (size_t)a.X * a.Y * a.Z;
+  if (id >= total) return 0;
+  if (!((a.active[id >> 5] >> (id & 31)) & 1u)) return 0;
+  k = (int)(id % a.Z);
+  j = (int)((id / a.Z) % a.Y);
+  i = (int)(id / ((size_t)a.Z * a.Y));
+  if (i >= a.X - 1 || j >= a.Y - 1 || k >= a.Z - 1) return 0;
+  if (i < a.mn[0] || j < a.mn[1] || k < a.mn[2] || i >= a.mx[0] || j >= a.mx[1] || k >= a.mx[2]) return 0;
+  cubeindex = 0;
+  bool invalid = false;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
+    const float v = ldh(a.vol, ((size_t)(i + dz) * a.Y + (j + dy)) * a.Z + (k + dx));
+    if (v < a.iso) cubeindex |= 1 << kCodeToVi[c];
+    if (v < -0.99999f) invalid = true;
+    val[c] = v;
+  }
+  if (invalid) return 0;
+  return 3 * (int)kMcTris[cubeindex];
+}
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& block_total) {
+  // 256 threads; simple Hillis-Steele in LDS
+  const int t = threadIdx.x;
+  lds[t] = v;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int add = (t >= off) ? lds[t - off] : 0;
+    __syncthreads();
+    lds[t] += add;
+    __syncthreads();
+  }
+  block_total = lds[255];
+  const int excl = lds[t] - v;
+  __syncthreads();
+  return excl;
+}
+
+__global__ __launch_bounds__(256) void mc_count_kernel(const McArgs a, int* __restrict__ block_sums,
+                                                      int* __restrict__ block_cells) {
+  __shared__ int lds[256];
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int i, j, k, ci;
+  float val[8];
+  const int n = classify(a, id, i, j, k, ci, val);
+  int tot;
+  block_exclusive_scan(n, lds, tot);
+  int cells;
+  block_exclusive_scan(n > 0 ? 1 : 0, lds, cells);
+  if (threadIdx.x == 0) {
+    block_sums[blockIdx.x] = tot;
+    block_cells[blockIdx.x] = cells;
+  }
+}
+
+// exclusive scan of block_sums in place (single block, 1024 threads, chunked) + totals
+__global__ __launch_bounds__(1024) void mc_scan_kernel(int* __restrict__ block_sums, const int* __restrict__ block_cells,
+                                                      int nblocks, int* __restrict__ counts_out) {
+  __shared__ long long part[1024];
+  __shared__ long long cpart[1024];
+  const int t = threadIdx.x;
+  const int per = (nblocks + 1023) / 1024;
+  const int b0 = t * per, b1 = min(b0 + per, nblocks);
+  long long s = 0, c = 0;
+  for (int b = b0; b < b1; ++b) {
+    s += block_sums[b];
+    c += block_cells[b];
+  }
+  part[t] = s;
+  cpart[t] = c;
+  __syncthreads();
+  if (t == 0) {
+    long long run = 0, crun = 0;
+    for (int q = 0; q < 1024; ++q) {
+      const long long v = part[q];
+      part[q] = run;
+      run += v;
+      crun += cpart[q];
+    }
+    counts_out[0] = (int)crun;
+    counts_out[1] = (run > 2147483647LL) ? -1 : (int)run;
+  }
+  __syncthreads();
+  long long run = part[t];
+  for (int b = b0; b < b1; ++b) {
+    const int v = block_sums[b];
+    block_sums[b] = (int)run;
+    run += v;
+  }
+}
+
+__device__ __forceinline__ void vertex_interp(float iso, float p1x, float p1y, float p1z, float p2x, float p2y,
+                                              float p2z, float v1, float v2, float& ox, float& oy, float& oz) {
+  const float eps = 1e-5f;
+  if (fabsf(iso - v1) < eps) {
+    ox = p1x; oy = p1y; oz = p1z;
+    return;
+  }
+  if (fabsf(iso - v2) < eps) {
+    ox = p2x; oy = p2y; oz = p2z;
+    return;
+  }
+  if (fabsf(v1 - v2) < eps) {
+    ox = p1x; oy = p1y; oz = p1z;
+    return;
+  }
+  const float ratio = (iso - v1) / (v2 - v1);
+  ox = p1x * (1 - ratio) + p2x * ratio;
+  oy = p1y * (1 - ratio) + p2y * ratio;
+  oz = p1z * (1 - ratio) + p2z * ratio;
+}
+
+__global__ __launch_bounds__(256) void mc_generate_kernel(const McArgs a, const int* __restrict__ block_offsets,
+                                                         float* __restrict__ verts, int64_t* __restrict__ faces,
+                                                         int64_t* __restrict__ ids, int num_verts) {
+  __shared__ int lds[256];
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int i = 0, j = 0, k = 0, ci = 0;
+  float val[8];
+  const int n = classify(a, id, i, j, k, ci, val);
+  int tot;
+  const int local = block_exclusive_scan(n, lds, tot);
+  if (n == 0) return;
+  const int base = block_offsets[blockIdx.x] + local;
+  // MC naming: x = k (Z axis, fastest), y = j, z = i;  W = Z, H = Y, D = X
+  const long long W = a.Z, H = a.Y, D = a.X;
+  const long long hash_mul = W + W * H + W * H * D;
+  for (int t = 0; t < n; ++t) {
+    const int e = kMcEdges[ci][t];
+    const int c1 = kEdgeCodes[e][0], c2 = kEdgeCodes[e][1];
+    const int x1 = k + (c1 & 1), y1 = j + ((c1 >> 1) & 1), z1 = i + ((c1 >> 2) & 1);
+    const int x2 = k + (c2 & 1), y2 = j + ((c2 >> 1) & 1), z2 = i + ((c2 >> 2) & 1);
+    float ox, oy, oz;
+    vertex_interp(a.iso, (float)x1, (float)y1, (float)z1, (float)x2, (float)y2, (float)z2, val[c1], val[c2], ox, oy, oz);
+    const int idx = base + t;
+    if (idx < num_verts) {
+      verts[(size_t)idx * 3 + 0] = ox;
+      verts[(size_t)idx * 3 + 1] = oy;
+      verts[(size_t)idx * 3 + 2] = oz;
+      const long long v1 = x1 + y1 * W + z1 * W * H, v2 = x2 + y2 * W + z2 * W * H;
+      ids[idx] = v1 * hash_mul + v2;
+      if (t % 3 == 0) {
+        const size_t f = (size_t)idx / 3;
+        faces[f * 3 + 0] = idx;
+        faces[f * 3 + 1] = idx + 1;
+        faces[f * 3 + 2] = idx + 2;
+      }
+    }
+  }
+}
+
+static int fill(McArgs& a, const uint16_t* vol, const uint32_t* active, int X, int Y, int Z, float iso, const int* mn,
+                const int* mx, const char* who) {
+  DT_REQUIRE(vol && active, "%s: null pointer", who);
+  DT_REQUIRE(X > 1 && Y > 1 && Z > 1, "%s: bad volume extent", who);
+  DT_REQUIRE(((size_t)X * Y * Z) % 256 == 0, "%s: voxel count must be a multiple of 256 (dims are multiples of 8)", who);
+  a.vol = vol;
+  a.active = active;
+  a.X = X;
+  a.Y = Y;
+  a.Z = Z;
+  a.iso = iso;
+  for (int q = 0; q < 3; ++q) {
+    a.mn[q] = mn ? mn[q] : -2147483647;
+    a.mx[q] = mx ? mx[q] : 2147483647;
+  }
+  return 0;
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+extern "C" {
+
+int64_t dt_mc_workspace_bytes(int X, int Y, int Z) {
+  const size_t nblocks = ((size_t)X * Y * Z + 255) / 256;
+  return (int64_t)(2 * nblocks * sizeof(int));
+}
+
+int dt_mc_count(const uint16_t* values, const uint32_t* active, int X, int Y, int Z, float isolevel, const int* mn,
+                const int* mx, void* workspace, int* counts_out, dt_stream_t s) {
+  McArgs a;
+  if (int rc = fill(a, values, active, X, Y, Z, isolevel, mn, mx, "dt_mc_count")) return rc;
+  DT_REQUIRE(workspace && counts_out, "dt_mc_count: null workspace");
+  const size_t nblocks = (size_t)X * Y * Z / 256;
+  DT_REQUIRE(nblocks < 2147483647ull, "dt_mc_count: volume too large");
+  int* sums = reinterpret_cast<int*>(workspace);
+  int* cells = sums + nblocks;
+  hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, to_stream(s), a, sums, cells);
+  hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, to_stream(s), sums, cells, (int)nblocks, counts_out);
+  return check_launch("dt_mc_count");
+}
+
+int dt_mc_generate(const uint16_t* values, const uint32_t* active, int X, int Y, int Z, float isolevel, const int* mn,
+                   const int* mx, const void* workspace, float* verts, int64_t* faces, int64_t* ids, int num_verts,
+                   dt_stream_t s) {
+  McArgs a;
+  if (int rc = fill(a, values, active, X, Y, Z, isolevel, mn, mx, "dt_mc_generate")) return rc;
+  DT_REQUIRE(workspace, "dt_mc_generate: null workspace");
+  DT_REQUIRE(num_verts >= 0 && num_verts % 3 == 0, "dt_mc_generate: num_verts=%d", num_verts);
+  if (num_verts == 0) return 0;
+  DT_REQUIRE(verts && faces && ids, "dt_mc_generate: null output");
+  const size_t nblocks = (size_t)X * Y * Z / 256;
+  hipLaunchKernelGGL(mc_generate_kernel, dim3((unsigned)nblocks), dim3(256), 0, to_stream(s), a,
+                     reinterpret_cast<const int*>(workspace), verts, faces, ids, num_verts);
+  return check_launch("dt_mc_generate");
+}
+
+}  // extern "C"

@@ -182,6 +182,9 @@ class FeatureVolumeManager(CostVolumeManager):
 
     _has_hint = False
     _fast_mask = True  # feature_volume.py:250-259: even the loop version returns any_k masks
+    #: optional callable(tag) invoked right before / after the fused kernel launch; bench.py uses
+    #: it to record HIP events on the launch stream (roofline timing)
+    _event_hook = None
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=None, matching_dim_size=16,
                  num_source_views=7):
@@ -260,6 +263,9 @@ class FeatureVolumeManager(CostVolumeManager):
             vol = torch.empty(b, D, h, w, device=dev, dtype=torch.float32, memory_format=torch.channels_last)
         else:
             vol = torch.empty(b, D, h, w, device=dev, dtype=torch.float32)
+        hook = FeatureVolumeManager._event_hook
+        if hook is not None:
+            hook("mlp_begin")
         if _impl == "mfma":
             _abi.check(L.dt_cv_mlp_hint_f32(
                 _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(pk["w1dyn"]), _abi.ptr(pk["w1pix"]),
@@ -273,6 +279,8 @@ class FeatureVolumeManager(CostVolumeManager):
                 "dt_cv_mlp_hint_simple_f32")
         else:
             raise ValueError(_impl)
+        if hook is not None:
+            hook("mlp_end")
         low = self._lowest(L, stream, vol, params, nhwc, dims)
         mask = None
         if return_mask:

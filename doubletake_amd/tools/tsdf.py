@@ -1,0 +1,244 @@
+"""fp16 TSDF volume + fuser with the reference's class/method names (reference tools/tsdf.py),
+on the HIP kernels of csrc/tsdf.hip and csrc/mc.hip.
+
+Differences by design:
+  * the [3,X,Y,Z] fp16 coordinate volume is not stored -- kernels recompute
+    half(fp32(origin) + idx*voxel_size) from the voxel index (``voxel_coords_3hwd`` materialises
+    it on demand for API users);
+  * the open3d HashSet of active keys is a device bitmap (``voxel_bitmap``; ``active_keys()``
+    lists it in ascending voxel order);
+  * GPU-resident only (no CPU fallback): ``cuda()`` / ``cpu()`` are accepted and ignored.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from .. import _abi
+from ..utils.pytorch3d_extras import bitmap_to_keys, marching_cubes
+
+
+class Meshes:
+    """Minimal stand-in for pytorch3d.structures.Meshes (not installed here): verts/faces lists."""
+
+    def __init__(self, verts, faces, textures=None):
+        self._verts, self._faces, self.textures = list(verts), list(faces), textures
+
+    def verts_list(self):
+        return self._verts
+
+    def faces_list(self):
+        return self._faces
+
+    def verts_packed(self):
+        return self._verts[0]
+
+    def faces_packed(self):
+        return self._faces[0]
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _abi.DoubletakeHipError("doubletake_amd TSDF needs a ROCm GPU (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class TSDF:
+    VOX_MOD = 8
+
+    def __init__(self, voxel_coords_3hwd, tsdf_values, tsdf_weights, voxel_size, origin, origin_f32=None, device=None):
+        """Reference signature (tools/tsdf.py:62-84) + the fp32 origin the coordinates were generated
+        from (TSDF.from_bounds passes it; when absent it is recovered from voxel_coords_3hwd)."""
+        dev = device or _device()
+        self.device = dev
+        self.voxel_size = float(voxel_size)
+        self.tsdf_values = tsdf_values.to(device=dev, dtype=torch.float16).contiguous()
+        self.tsdf_weights = tsdf_weights.to(device=dev, dtype=torch.float16).contiguous()
+        self.origin = origin.to(dtype=torch.float16).cpu()
+        X, Y, Z = self.tsdf_values.shape
+        if origin_f32 is None:
+            # the half origin is not enough to regenerate the coordinates bit-for-bit; check it
+            o = self.origin.float().numpy()
+            regen = self.generate_voxel_coords(torch.from_numpy(o), (X, Y, Z), self.voxel_size).half()
+            if voxel_coords_3hwd is None or not torch.equal(regen, voxel_coords_3hwd.half().cpu()):
+                raise NotImplementedError("voxel_coords_3hwd is not origin + idx*voxel_size with the stored (half) origin")
+            origin_f32 = o
+        self.origin_f32 = np.asarray(origin_f32, dtype=np.float32).reshape(3)
+        self.voxel_bitmap = torch.zeros((X * Y * Z) // 32, dtype=torch.int32, device=dev)
+        self._mc_ws = None
+
+    # -- constructors ---------------------------------------------------------------------------
+    @classmethod
+    def from_file(cls, tsdf_file):
+        data = np.load(tsdf_file)
+        return cls(torch.from_numpy(data["voxel_coords_3hwd"]), torch.from_numpy(data["tsdf_values"]),
+                   torch.from_numpy(data["tsdf_weights"]), data["voxel_size"].item(), torch.from_numpy(data["origin"]))
+
+    @classmethod
+    def from_mesh(cls, mesh, voxel_size: float):
+        """mesh: anything with a .vertices [N,3] array (tools/tsdf.py:99-120: bounds padded by 3 voxels)."""
+        v = np.asarray(mesh.vertices)
+        xmax, ymax, zmax = v.max(0)
+        xmin, ymin, zmin = v.min(0)
+        bounds = {"xmin": xmin, "xmax": xmax, "ymin": ymin, "ymax": ymax, "zmin": zmin, "zmax": zmax}
+        for key, val in bounds.items():
+            bounds[key] = val - 3 * voxel_size if "min" in key else val + 3 * voxel_size
+        return cls.from_bounds(bounds, voxel_size)
+
+    @classmethod
+    def volume_dims(cls, bounds: dict, voxel_size: float):
+        """tools/tsdf.py:134-142 -- integer arithmetic on Python floats, identical on every backend."""
+        for key in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax"):
+            if key not in bounds:
+                raise KeyError("Provided bounds dict need to have keys'xmin', 'xmax', 'ymin', 'ymax', 'zmin', 'zmax'!")
+        return tuple(int(np.ceil((bounds[a + "max"] - bounds[a + "min"]) / voxel_size / cls.VOX_MOD)) * cls.VOX_MOD
+                     for a in "xyz")
+
+    @classmethod
+    def from_bounds(cls, bounds: dict, voxel_size: float, device=None):
+        dims = cls.volume_dims(bounds, voxel_size)
+        dev = device or _device()
+        origin = torch.FloatTensor([bounds["xmin"], bounds["ymin"], bounds["zmin"]])
+        values = -torch.ones(dims, dtype=torch.float16, device=dev)
+        weights = torch.zeros(dims, dtype=torch.float16, device=dev)
+        return cls(None, values, weights, voxel_size, origin, origin_f32=origin.numpy().copy(), device=dev)
+
+    @classmethod
+    def generate_voxel_coords(cls, origin: torch.Tensor, volume_dims: Tuple[int, int, int], voxel_size: float):
+        grid = torch.meshgrid([torch.arange(vd) for vd in volume_dims], indexing="ij")
+        return origin.view(3, 1, 1, 1) + torch.stack(grid, 0) * voxel_size
+
+    @property
+    def voxel_coords_3hwd(self):
+        c = self.generate_voxel_coords(torch.from_numpy(self.origin_f32), tuple(self.tsdf_values.shape), self.voxel_size)
+        return c.half().to(self.device)
+
+    def cuda(self):
+        return self
+
+    def cpu(self):
+        return self
+
+    # -- active set ---------------------------------------------------------------------------------
+    def active_keys(self):
+        """[N,3] int32 keys of the active voxels (what the reference keeps in its HashSet)."""
+        return bitmap_to_keys(self.voxel_bitmap, tuple(self.tsdf_values.shape))
+
+    # -- meshing --------------------------------------------------------------------------------------
+    def to_mesh_pytorch3d(self, scale_to_world=True, min_bounds_3=None, max_bounds_3=None):
+        """tools/tsdf.py:216-255 -> (Meshes, verts, faces)."""
+        dev = self.device
+        org = self.origin.float().to(dev)
+        mn = torch.floor((min_bounds_3.to(dev) - org) / self.voxel_size).int() if min_bounds_3 is not None else None
+        mx = torch.ceil((max_bounds_3.to(dev) - org) / self.voxel_size).int() if max_bounds_3 is not None else None
+        bv, bf = marching_cubes(self.tsdf_values[None], self.voxel_bitmap, isolevel=0.0, return_local_coords=False,
+                                min_bounds=mn, max_bounds=mx)
+        verts, faces = bv[0], bf[0]
+        if len(verts) == 0:
+            verts = torch.zeros(1, 3, device=dev)
+            faces = torch.zeros(1, 3, device=dev)
+        if scale_to_world:
+            verts = self.origin.view(1, 3).to(dev) + verts * self.voxel_size
+        return Meshes(verts=[verts], faces=[faces]), verts, faces
+
+    def to_mesh(self, scale_to_world=True, export_single_mesh=False):
+        raise NotImplementedError(
+            "final mesh export goes through a scikit-image fork on CPU in the reference (tools/tsdf.py:182-214); "
+            "out of scope (SURVEY.md section 8a M2) -- use to_mesh_pytorch3d()")
+
+    def save_tsdf(self, filepath):
+        """tools/tsdf.py:267-275 (same npz keys)."""
+        np.savez_compressed(
+            filepath,
+            tsdf_values=self.tsdf_values.cpu().numpy().astype(np.float16),
+            tsdf_weights=self.tsdf_weights.cpu().numpy().astype(np.float16),
+            origin=self.origin.cpu().numpy().astype(np.float16),
+            voxel_coords_3hwd=self.voxel_coords_3hwd.cpu().numpy().astype(np.float16),
+            voxel_size=self.voxel_size,
+        )
+
+    # -- sampling ---------------------------------------------------------------------------------------
+    def sample_tsdf(self, world_points_N3, what_to_sample="tsdf", sampling_method="bilinear", fp16_math=False):
+        """tools/tsdf.py:277-339 (trilinear, align_corners=True).  fp32 math on the half volume (the
+        reference's pinned CPU branch) unless fp16_math=True."""
+        if not (world_points_N3.ndim == 2 and world_points_N3.shape[1] == 3):
+            raise ValueError("world_points_N3 must have shape (N, 3)! Instead got shape {}".format(world_points_N3.shape))
+        if sampling_method not in ("bilinear", "trilinear"):
+            raise NotImplementedError("only trilinear sampling is used by the reference drivers")
+        if what_to_sample not in ("tsdf", "weights"):
+            raise ValueError(what_to_sample)
+        L = _abi.lib()
+        dev = self.device
+        pts = world_points_N3.to(device=dev, dtype=torch.float32).contiguous()
+        vol = self.tsdf_values if what_to_sample == "tsdf" else self.tsdf_weights
+        out = torch.empty(pts.shape[0], dtype=torch.float32, device=dev)
+        X, Y, Z = vol.shape
+        o = (C.c_float * 3)(*[float(v) for v in self.origin.float().tolist()])
+        _abi.check(L.dt_tsdf_sample_f16(_abi.ptr(vol), o, self.voxel_size, X, Y, Z, _abi.ptr(pts), _abi.ptr(out),
+                                        pts.shape[0], int(fp16_math), _abi.current_stream(dev)), "dt_tsdf_sample_f16")
+        return out.half() if fp16_math else out
+
+
+class TSDFFuser:
+    """Reference tools/tsdf.py:342-558."""
+
+    def __init__(self, tsdf, min_depth=0.5, max_depth=5.0, use_gpu=True):
+        if not use_gpu:
+            raise _abi.DoubletakeHipError("the doubletake_amd fuser is GPU-only")
+        self.tsdf = tsdf
+        self.min_depth = min_depth
+        self.max_depth = max_depth
+        self.use_gpu = True
+        self.truncation_size = 3.0
+        self.maxW = 100.0
+        L = _abi.lib()
+        self._frame_params = torch.empty(L.dt_tsdf_frame_params_floats(), dtype=torch.float32, device=tsdf.device)
+
+    voxel_size = property(lambda self: self.tsdf.voxel_size)
+    tsdf_values = property(lambda self: self.tsdf.tsdf_values)
+    tsdf_weights = property(lambda self: self.tsdf.tsdf_weights)
+    shape = property(lambda self: self.tsdf.tsdf_values.shape)
+    truncation = property(lambda self: self.truncation_size * self.voxel_size)
+
+    def _thresholds(self, extended_neg_truncation):
+        trunc = self.truncation
+        th = _abi.TsdfThresholds()
+        th.trunc = float(np.float32(trunc))
+        th.thr_neg = float(np.float16(-trunc * 1.5 if extended_neg_truncation else -trunc))
+        th.thr_pos = float(np.float16(trunc))
+        th.max_depth_h = float(np.float16(self.max_depth))
+        th.min_depth = float(np.float32(self.min_depth))
+        th.depth_range = float(np.float32(self.max_depth - self.min_depth))
+        return th
+
+    @torch.no_grad()
+    def integrate_depth(self, depth_b1hw, cam_T_world_T_b44, K_b44, depth_mask_b1hw=None, extended_neg_truncation=False):
+        """Integrates depth maps into the volume, frame by frame in batch order (tools/tsdf.py:414-558)."""
+        L = _abi.lib()
+        t = self.tsdf
+        dev = t.device
+        stream = _abi.current_stream(dev)
+        depth = depth_b1hw.to(dev)
+        if depth_mask_b1hw is not None:
+            depth = depth.clone()
+            depth[~depth_mask_b1hw.to(dev)] = -1
+        depth = depth.half().contiguous()
+        K16 = K_b44.to(dev).half().contiguous()
+        T16 = cam_T_world_T_b44.to(dev).half().contiguous()
+        img_h, img_w = depth.shape[2:]
+        X, Y, Z = t.tsdf_values.shape
+        th = self._thresholds(extended_neg_truncation)
+        depth_min = 0.01
+        depth_max = self.max_depth + self.truncation + 0.1
+        o = (C.c_float * 3)(*[float(v) for v in t.origin_f32])
+        for b in range(depth.shape[0]):
+            _abi.check(L.dt_tsdf_frame_setup_f16(_abi.ptr(K16[b]), _abi.ptr(T16[b]), img_h, img_w, float(np.float32(depth_min)),
+                                                 float(np.float32(depth_max)), _abi.ptr(self._frame_params), stream),
+                       "dt_tsdf_frame_setup_f16")
+            _abi.check(L.dt_tsdf_integrate_f16(_abi.ptr(t.tsdf_values), _abi.ptr(t.tsdf_weights), _abi.ptr(t.voxel_bitmap), o,
+                                               float(np.float32(t.voxel_size)), X, Y, Z, _abi.ptr(depth[b, 0]), img_h, img_w,
+                                               _abi.ptr(self._frame_params), C.byref(th), stream), "dt_tsdf_integrate_f16")

@@ -156,21 +156,35 @@ int dt_exp_f32(const float* in, float* out, int64_t count, dt_stream_t s);
 /* ---- TSDF fusion -----------------------------------------------------------------------
  * Volume: values/weights fp16 [X,Y,Z] (Z fastest), voxel (i,j,k) centre =
  * half(float(origin) + (i,j,k)*voxel_size) as in TSDF.generate_voxel_coords
- * (tools/tsdf.py:157-166).  `active` is a bitmap of X*Y*Z bits (uint32 words) replacing
- * the open3d HashSet of active voxel keys (tools/tsdf.py:79-84,530-538).
+ * (tools/tsdf.py:157-166).  `active` is a bitmap of X*Y*Z bits (uint32 words, bit id&31 of word
+ * id>>5, id = (i*Y + j)*Z + k) replacing the open3d HashSet of active voxel keys
+ * (tools/tsdf.py:79-84,530-538).  uint16_t* = IEEE half bits.
  */
-/* replaces: TSDFFuser.integrate_depth for ONE frame (tools/tsdf.py:444-558) incl.
- * get_frustum_bounds (:15-50) and project_to_camera (:401-412); fp16-faithful.
- * frame_params: 48 floats prepared on the host by doubletake_amd.tools.tsdf
- * (half-rounded K@T rows, frustum AABB, image size; see tsdf.hip). */
+int dt_tsdf_frame_params_floats(void);
+/* replaces the per-frame prologue of TSDFFuser.integrate_depth (tools/tsdf.py:446-455):
+ * inverse of K and cam_T_world (fp32 -> half), get_frustum_bounds (:15-50), P = K @ T (:407).
+ * K16_44 / T16_44: device, 16 halves each.  frame_params: device, dt_tsdf_frame_params_floats. */
+int dt_tsdf_frame_setup_f16(const uint16_t* K16_44, const uint16_t* T16_44, int img_h, int img_w,
+                            float depth_min, float depth_max, float* frame_params, dt_stream_t s);
+
+/* scalar thresholds of one fuser, prepared on the host with the reference's rounding points
+ * (doubletake_amd/tools/tsdf.py: trunc = fp32(3*vs); thr_neg = half(-trunc [*1.5]);
+ * thr_pos = half(trunc); max_depth_h = half(max_depth); depth_range = fp32(max - min)). */
+typedef struct dt_tsdf_thresholds {
+  float trunc, thr_neg, thr_pos, max_depth_h, min_depth, depth_range;
+} dt_tsdf_thresholds;
+
+/* replaces: the per-voxel body of TSDFFuser.integrate_depth for ONE frame (tools/tsdf.py:457-558)
+ * incl. project_to_camera (:401-412); fp16-faithful (one rounding per reference op).
+ * origin3: HOST pointer to the 3 fp32 origin components; depth_hw_f16: device [img_h,img_w]. */
 int dt_tsdf_integrate_f16(uint16_t* values, uint16_t* weights, uint32_t* active,
                           const float* origin3, float voxel_size, int X, int Y, int Z,
                           const uint16_t* depth_hw_f16, int img_h, int img_w,
-                          const float* frame_params, float max_depth, float min_depth,
-                          int extended_neg_truncation, dt_stream_t s);
+                          const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s);
 /* replaces: TSDF.sample_tsdf (tools/tsdf.py:277-339), trilinear, align_corners=True, zeros
- * padding.  fp16_math = 1 reproduces the reference's GPU branch (volume dtype half),
- * 0 its CPU branch (fp32). */
+ * padding.  fp16_math = 0 reproduces the reference's CPU branch (fp32 math on the half volume,
+ * pinned by goldens); 1 rounds grid and result to half like its GPU branch (unpinned).
+ * origin3: HOST pointer (the half-rounded origin the reference keeps, as fp32). */
 int dt_tsdf_sample_f16(const uint16_t* volume, const float* origin3, float voxel_size,
                        int X, int Y, int Z, const float* points_n3, float* out_n,
                        int64_t n, int fp16_math, dt_stream_t s);
@@ -178,16 +192,19 @@ int dt_tsdf_sample_f16(const uint16_t* volume, const float* origin3, float voxel
 /* ---- marching cubes over the active-voxel set -------------------------------------------
  * replaces: marching_cubes_(vol, isolevel, active_voxels, min_bounds, max_bounds)
  * (tools/marching_cubes/ext.cpp:4-6, marching_cubes.h:47-69, marching_cubes.cu:455-597)
- * with the CUDA path's semantics (active list, bounds, "corner < -0.99999 => skip").
- * Two-phase: dt_mc_count writes per-cell vertex counts + exclusive scan and the total into
- * counts_out[0] (cells) / counts_out[1] (vertices) on the DEVICE; the caller reads the two
- * ints once, allocates, and calls dt_mc_generate.
+ * with the CUDA path's semantics (active set, bounds, "corner < -0.99999 => skip").
+ * Two-phase: dt_mc_count leaves per-block offsets in `workspace` and writes
+ * counts_out[0] = cells, counts_out[1] = vertices (device ints; -1 on int overflow); the caller
+ * reads them once, allocates verts [V,3] f32 / faces [V/3,3] i64 / ids [V] i64 and calls
+ * dt_mc_generate with the same arguments.  min_bounds3 / max_bounds3: HOST int[3] in (i,j,k)
+ * order or NULL.  Output vertex coordinates use the reference's (x,y,z) = (k,j,i) order.
  */
 int64_t dt_mc_workspace_bytes(int X, int Y, int Z);
 int dt_mc_count(const uint16_t* values_f16, const uint32_t* active, int X, int Y, int Z,
                 float isolevel, const int* min_bounds3, const int* max_bounds3,
                 void* workspace, int* counts_out, dt_stream_t s);
-int dt_mc_generate(const uint16_t* values_f16, int X, int Y, int Z, float isolevel,
+int dt_mc_generate(const uint16_t* values_f16, const uint32_t* active, int X, int Y, int Z,
+                   float isolevel, const int* min_bounds3, const int* max_bounds3,
                    const void* workspace, float* verts_v3, int64_t* faces_f3, int64_t* ids_v,
                    int num_verts, dt_stream_t s);
 

@@ -1,0 +1,70 @@
+"""The C-ABI library builds, loads without a GPU and exports every symbol include/doubletake_hip.h
+declares; argument validation fails loudly before any launch.  CPU only (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+HEADER = os.path.join(os.path.dirname(__file__), "..", "include", "doubletake_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from doubletake_amd import _abi
+
+    L = _abi.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in doubletake_hip.h but not exported"
+    # and the Python binding table covers exactly the header
+    assert sorted(_abi.SIGNATURES) == syms
+    assert L.dt_version() >= 100
+
+
+def test_argument_errors_are_reported_not_launched():
+    from doubletake_amd import _abi
+
+    L = _abi.lib()
+    assert L.dt_cv_setup_f32(None, None, None, None, None, None, 1, 7, 64, None, None) != 0
+    assert b"null pointer" in L.dt_last_error()
+    assert L.dt_cv_dot_f32(None, None, None, None, 1, 7, 12, 4, 4, 8, None) != 0
+    assert b"channels" in L.dt_last_error() or b"null" in L.dt_last_error()
+    n = ctypes.c_int()
+    assert L.dt_cv_mlp_pack_floats(9, ctypes.byref(n), None, None, None) != 0
+    assert L.dt_cv_mlp_pack_floats(7, ctypes.byref(n), None, None, None) == 0 and n.value == 7 * 12 * 256
+    assert L.dt_conv_pack_floats(64, 64, 3) == 64 * 64 * 9
+    d = _abi.ConvDesc()
+    assert L.dt_conv2d_f32(ctypes.byref(d), None, None, None, None, None, None, None, None) != 0
+    with pytest.raises(_abi.DoubletakeHipError):
+        _abi.check(1, "x")
+
+
+def test_no_cpu_fallback_in_product_modules():
+    import torch
+
+    from doubletake_amd import _abi
+    from doubletake_amd.modules.cost_volume import CostVolumeManager
+    from doubletake_amd.modules.layers import BasicBlock
+
+    m = CostVolumeManager(8, 8, 4)
+    z = torch.zeros
+    with pytest.raises(_abi.DoubletakeHipError):
+        m(z(1, 16, 8, 8), z(1, 2, 16, 8, 8), z(1, 2, 4, 4), z(1, 2, 4, 4), z(1, 2, 4, 4), z(1, 4, 4), z(1), z(1))
+    with pytest.raises(_abi.DoubletakeHipError):
+        BasicBlock(32, 32)(z(1, 32, 8, 8))
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.join(os.path.dirname(__file__), "..", "doubletake_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f

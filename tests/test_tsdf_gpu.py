@@ -1,0 +1,154 @@
+"""GPU parity of the fp16 TSDF fuser / sampler and the active-voxel marching cubes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from doubletake_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+BD = dict(xmin=-1.28, xmax=1.28, ymin=-1.12, ymax=1.12, zmin=0.0, zmax=2.24)
+RUNS = {"a": (0.04, 3.0, False, 120, 160, 3), "b": (0.04, 3.0, True, 96, 128, 4)}
+
+
+def _run(tag, nframes=5):
+    import gpu_util as gu
+    from doubletake_amd.tools.fusers_helper import OurFuser
+    from oracle import tsdf_ref as tr
+
+    vs, maxd, ext, H, W, seed = RUNS[tag]
+    depth, K, T = syn.tsdf_frames(5, H, W, seed=seed, bounds=BD)
+    depth = depth * np.float32(0.6)
+    fuser = OurFuser(gt_path=None, fusion_resolution=vs, max_fusion_depth=maxd, extended_neg_truncation=ext, bounds=BD)
+    vol = tr.TSDFVolume(BD, vs)
+    undefined = np.zeros(vol.values.size, dtype=bool)
+    snaps = {}
+    for f in range(nframes):
+        fuser.fuse_frames(torch.from_numpy(depth[f:f + 1]).to(gu.dev()), torch.from_numpy(K[f:f + 1]).to(gu.dev()),
+                          torch.from_numpy(T[f:f + 1]).to(gu.dev()), None)
+        tr.integrate(vol, depth[f, 0], K[f], T[f], maxd, extended_neg_truncation=ext)
+        undefined[vol.last_undefined_ids] = True
+        t = fuser.tsdf_fuser_pred.tsdf
+        snaps[f + 1] = (t.tsdf_values.cpu().numpy().copy(), t.tsdf_weights.cpu().numpy().copy(),
+                        t.active_keys().cpu().numpy().astype(np.int64), vol.values.copy(), vol.weights.copy(),
+                        np.array(sorted(vol.active), dtype=np.int64).reshape(-1, 3), undefined.copy())
+    return fuser, vol, snaps
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_integrate_bit_exact_vs_oracle_and_reference_golden(tag):
+    g = load_golden("tsdf.npz")
+    fuser, vol, snaps = _run(tag)
+    assert list(fuser.tsdf_fuser_pred.tsdf.tsdf_values.shape) == list(g[f"int_{tag}_dims"])
+    for n in (1, 2, 5):
+        gv, gw, gk, ov, ow, ok_, undef = snaps[n]
+        # vs the numpy oracle: every voxel, bit for bit
+        np.testing.assert_array_equal(gv.view(np.uint16), ov.view(np.uint16))
+        np.testing.assert_array_equal(gw.view(np.uint16), ow.view(np.uint16))
+        np.testing.assert_array_equal(gk, ok_)
+        # vs the reference's own CPU-half run (golden), except where its sampler hits C++ UB
+        keep = ~undef
+        np.testing.assert_array_equal(gv.reshape(-1)[keep].view(np.uint16), g[f"int_{tag}_vals_{n}"].reshape(-1)[keep].view(np.uint16))
+        np.testing.assert_array_equal(gw.reshape(-1)[keep].view(np.uint16), g[f"int_{tag}_wts_{n}"].reshape(-1)[keep].view(np.uint16))
+        np.testing.assert_array_equal(gk, g[f"int_{tag}_active_{n}"])  # the integer active-key set
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_sample_tsdf_vs_reference_golden(tag):
+    import gpu_util as gu
+
+    g = load_golden("tsdf.npz")
+    fuser, _, _ = _run(tag)
+    t = fuser.tsdf_fuser_pred.tsdf
+    # sample the golden volume itself so the comparison is independent of the UB voxels
+    t.tsdf_values.copy_(torch.from_numpy(g[f"int_{tag}_vals_5"]).to(gu.dev()))
+    t.tsdf_weights.copy_(torch.from_numpy(g[f"int_{tag}_wts_5"]).to(gu.dev()))
+    pts = torch.from_numpy(g[f"sample_{tag}_pts"]).to(gu.dev())
+    np.testing.assert_allclose(fuser.sample_tsdf(pts, "weights").cpu().numpy(), g[f"sample_{tag}_weights"], atol=1e-6)
+    np.testing.assert_allclose(fuser.sample_tsdf(pts, "tsdf").cpu().numpy(), g[f"sample_{tag}_tsdf"], atol=1e-6)
+
+
+def test_batched_integrate_equals_sequential():
+    import gpu_util as gu
+    from doubletake_amd.tools.fusers_helper import OurFuser
+
+    vs, maxd, ext, H, W, seed = RUNS["a"]
+    depth, K, T = syn.tsdf_frames(4, H, W, seed=seed, bounds=BD)
+    depth = depth * np.float32(0.6)
+    d, k, t = (torch.from_numpy(a).to(gu.dev()) for a in (depth, K, T))
+    f1 = OurFuser(None, vs, maxd, bounds=BD)
+    f2 = OurFuser(None, vs, maxd, bounds=BD)
+    f1.fuse_frames(d, k, t, None)
+    for i in range(4):
+        f2.fuse_frames(d[i:i + 1], k[i:i + 1], t[i:i + 1], None)
+    a, b = f1.tsdf_fuser_pred.tsdf, f2.tsdf_fuser_pred.tsdf
+    assert torch.equal(a.tsdf_values, b.tsdf_values) and torch.equal(a.tsdf_weights, b.tsdf_weights)
+    assert torch.equal(a.voxel_bitmap, b.voxel_bitmap)
+
+
+def test_marching_cubes_vs_oracle_on_fused_volume():
+    from doubletake_amd.utils.pytorch3d_extras import marching_cubes_raw
+    from oracle import mc_ref
+
+    fuser, vol, snaps = _run("a", nframes=3)
+    t = fuser.tsdf_fuser_pred.tsdf
+    keys = t.active_keys().cpu().numpy().astype(np.int64)
+    v, f, ids = marching_cubes_raw(t.tsdf_values, t.voxel_bitmap, 0.0)
+    ov, of, oids = mc_ref.marching_cubes_active(vol.values.astype(np.float32), keys, 0.0)
+    assert len(f) == len(of) > 500
+    # same order too (ascending voxel id), so compare directly
+    np.testing.assert_allclose(v.cpu().numpy(), ov, atol=1e-5)
+    np.testing.assert_array_equal(ids.cpu().numpy(), oids)
+    np.testing.assert_array_equal(f.cpu().numpy(), of)
+    # reference wrapper post-processing (dedup by edge id, axis flip, world scale)
+    mesh, wv, wf = fuser.get_mesh_pytorch3d()
+    pv, pf = mc_ref.postprocess(ov, of, oids)
+    want_v = t.origin.float().numpy().reshape(1, 3) + pv * np.float32(t.voxel_size)
+    np.testing.assert_allclose(wv.cpu().numpy(), want_v, atol=1e-4)
+    np.testing.assert_array_equal(wf.cpu().numpy(), pf)
+    assert mesh.verts_list()[0].shape[1] == 3
+    # bounds argument restricts cells (CUDA semantics: min <= g < max)
+    mn, mx = [0, 0, 0], [30, 56, 56]
+    v2, f2, _ = marching_cubes_raw(t.tsdf_values, t.voxel_bitmap, 0.0, mn, mx)
+    ov2, of2, _ = mc_ref.marching_cubes_active(vol.values.astype(np.float32), keys, 0.0, mn, mx)
+    assert len(f2) == len(of2) and 0 < len(f2) < len(f)
+
+
+def test_marching_cubes_matches_reference_cpu_semantics_where_they_coincide():
+    """Dense active set, no unobserved corners: triangle set equals the (golden-pinned) oracle's."""
+    import gpu_util as gu
+    from doubletake_amd.utils.pytorch3d_extras import keys_to_bitmap, marching_cubes_raw
+    from oracle import mc_ref
+
+    n = 16
+    g = np.stack(np.meshgrid(*[np.arange(n, dtype=np.float32)] * 3, indexing="ij"), -1)
+    vol = (np.linalg.norm(g - np.array([7.3, 7.71, 6.9], dtype=np.float32), axis=-1) - np.float32(4.37)) * np.float32(0.2)
+    vol = np.clip(vol, -0.9, 0.9).astype(np.float16)
+    keys = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    tv = torch.from_numpy(vol).to(gu.dev())
+    bm = keys_to_bitmap(torch.from_numpy(keys).to(gu.dev()), (n, n, n))
+    v, f, ids = marching_cubes_raw(tv, bm, 0.0)
+    ov, of, _ = mc_ref.marching_cubes_active(vol.astype(np.float32), keys, 0.0)
+    assert mc_ref.triangle_set(v.cpu().numpy(), f.cpu().numpy()) == mc_ref.triangle_set(ov, of)
+
+
+def test_full_size_volume_one_frame_vs_oracle():
+    """BASELINE-size fuser: 8 x 8 x 3.2 m at 0.04 m (200x200x80), 480x640 frame, vs the oracle bit for bit."""
+    import gpu_util as gu
+    from doubletake_amd.tools.fusers_helper import OurFuser
+    from oracle import tsdf_ref as tr
+
+    bd = dict(xmin=-4.0, xmax=4.0, ymin=-4.0, ymax=4.0, zmin=0.0, zmax=3.2)
+    depth, K, T = syn.tsdf_frames(2, 480, 640, seed=9, bounds=bd)
+    fuser = OurFuser(None, 0.04, 3.0, bounds=bd)
+    vol = tr.TSDFVolume(bd, 0.04)
+    for f in range(2):
+        fuser.fuse_frames(*(torch.from_numpy(a[f:f + 1]).to(gu.dev()) for a in (depth, K, T)), None)
+        tr.integrate(vol, depth[f, 0], K[f], T[f], 3.0)
+    t = fuser.tsdf_fuser_pred.tsdf
+    np.testing.assert_array_equal(t.tsdf_values.cpu().numpy().view(np.uint16), vol.values.view(np.uint16))
+    np.testing.assert_array_equal(t.tsdf_weights.cpu().numpy().view(np.uint16), vol.weights.view(np.uint16))
+    np.testing.assert_array_equal(t.active_keys().cpu().numpy().astype(np.int64),
+                                  np.array(sorted(vol.active), dtype=np.int64).reshape(-1, 3))
+    assert len(vol.active) > 10000
