@@ -44,26 +44,37 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 constexpr int kPH = 4, kPW = 8;  // output patch of one MFMA pixel block
 
-template <int KS, int ST>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+// SPLIT = number of waves that share one 32-channel x 32-pixel output block by splitting K:
+//   1  : every wave owns a whole block (4 blocks per 256-thread workgroup), no reduction;
+//        used when the layer has enough blocks to fill the chip on its own
+//   4  : one block per 256-thread workgroup, 4-way K split, LDS reduction
+//   16 : one block per 1024-thread workgroup, 16-way K split (the 15x20 / 30x40 levels)
+template <int KS, int ST, int SPLIT>
+__global__ __launch_bounds__(SPLIT == 16 ? 1024 : 256) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int NW = (SPLIT == 16) ? 16 : 4;
   constexpr int IH = (kPH - 1) * ST + KS, IW = (kPW - 1) * ST + KS;
   constexpr int NPIX = IH * IW;
-  constexpr int TILE_FLOATS = (NPIX * 8 > 1024) ? NPIX * 8 : 1024;
+  constexpr int NLOAD = (NPIX + 31) / 32;  // float4 staging loads per lane and group
+  constexpr int TILE_FLOATS = (SPLIT == 1) ? NPIX * 8 : ((NPIX * 8 > 1024) ? NPIX * 8 : 1024);
   constexpr int PAD = KS / 2;
-  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];
+  constexpr int TAPS = KS * KS;
+  __shared__ __attribute__((aligned(16))) float lds[NW * TILE_FLOATS];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, p = lane & 31;
   const int py = p >> 3, px = p & 7;
 
-  int bid = blockIdx.x;
-  const int cb = bid % a.co_blocks;
+  const long total_blocks = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
+  long bid = (SPLIT == 1) ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x;
+  const bool have_block = bid < total_blocks;
+  if (!have_block) bid = total_blocks - 1;  // keep the wave alive (no barriers are skipped); it stores nothing
+  const int cb = (int)(bid % a.co_blocks);
   bid /= a.co_blocks;
-  const int tx = bid % a.tiles_x;
+  const int tx = (int)(bid % a.tiles_x);
   bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y;
-  const int n = bid / a.tiles_y;
+  const int ty = (int)(bid % a.tiles_y);
+  const int n = (int)(bid / a.tiles_y);
 
   const int oy = ty * kPH + py, ox = tx * kPW + px;
   const int iy0 = ty * kPH * ST - PAD, ix0 = tx * kPW * ST - PAD;
@@ -73,11 +84,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  const int taps = KS * KS;
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
+  const int g_first = (SPLIT == 1) ? 0 : wave;
+  const int g_step = (SPLIT == 1) ? 1 : SPLIT;
 
-  for (int g = wave; g < a.groups; g += 4) {
-    // locate the source of this 8-channel group
+  float4 patch[NLOAD];
+  float4 wnext[TAPS];
+
+  // issue the global loads of one 8-channel group: its input patch and its 9 (or 1) weight fragments
+  auto prefetch = [&](int g) {
     int s = 0, gl = g;
     while (s + 1 < a.nsrc && gl >= (a.c[s] >> 3)) {
       gl -= a.c[s] >> 3;
@@ -86,54 +101,56 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const float* sp = a.src[s];
     const int cs = a.c[s], up = a.up[s];
     const int hs = up ? (a.h_in >> 1) : a.h_in, ws = up ? (a.w_in >> 1) : a.w_in;
-    // ---- stage the (IH x IW) x 8-channel input patch of this wave -------------------------
-    __builtin_amdgcn_wave_barrier();
-    for (int idx = lane >> 1; idx < NPIX; idx += 32) {
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int idx = (lane >> 1) + it * 32;
       const int ly = idx / IW, lx = idx - ly * IW;
       const int iy = iy0 + ly, ix = ix0 + lx;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) {
+      if (idx < NPIX && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) {
         const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
         v = *reinterpret_cast<const float4*>(sp + (((size_t)n * hs + sy) * ws + sx) * cs + gl * 8 + (lane & 1) * 4);
       }
-      *reinterpret_cast<float4*>(tile + idx * 8 + (lane & 1) * 4) = v;
+      patch[it] = v;
     }
+    const float4* wg = wp4 + ((size_t)(cb * a.groups + g) * TAPS * 2 + half) * 32 + p;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) wnext[t] = wg[(size_t)t * 64];
+  };
+
+  if (g_first < a.groups) prefetch(g_first);
+  for (int g = g_first; g < a.groups; g += g_step) {
+    // ---- publish the prefetched patch to this wave's LDS tile ---------------------------------
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int idx = (lane >> 1) + it * 32;
+      if (idx < NPIX) *reinterpret_cast<float4*>(tile + idx * 8 + (lane & 1) * 4) = patch[it];
+    }
+    float4 wcur[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) wcur[t] = wnext[t];
+    // ---- next group's loads fly while this group's MFMAs run ------------------------------------
+    if (g + g_step < a.groups) prefetch(g + g_step);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- taps -------------------------------------------------------------------------------
-    const float4* wg = wp4 + ((size_t)(cb * a.groups + g) * taps * 2 + half) * 32 + p;
 #pragma unroll
-    for (int t = 0; t < KS * KS; ++t) {
+    for (int t = 0; t < TAPS; ++t) {
       const int ky = t / KS, kx = t - ky * KS;
-      const float4 a4 = wg[(size_t)t * 64];
       const float4 b4 = *reinterpret_cast<const float4*>(tile + ((py * ST + ky) * IW + (px * ST + kx)) * 8 + half * 4);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].w, b4.w, acc, 0, 0, 0);
     }
   }
 
-  // ---- cross-wave K reduction + fused epilogue ----------------------------------------------
-  __syncthreads();  // every wave is done reading its patch
-#pragma unroll
-  for (int r = 0; r < 16; ++r) tile[r * 64 + lane] = acc[r];
-  __syncthreads();
-  float4 o;
-  {
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = wave * 4 + j;
-      v[j] = lds[0 * TILE_FLOATS + r * 64 + lane] + lds[1 * TILE_FLOATS + r * 64 + lane] +
-             lds[2 * TILE_FLOATS + r * 64 + lane] + lds[3 * TILE_FLOATS + r * 64 + lane];
-    }
-    o = make_float4(v[0], v[1], v[2], v[3]);
-  }
-  if (oy < a.h_out && ox < a.w_out) {
-    const int co = cb * 32 + wave * 8 + half * 4;
-    const size_t off = (((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out + co;
+  const bool in_image = have_block && oy < a.h_out && ox < a.w_out;
+  const size_t pix_off = (((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out;
+
+  auto finish = [&](float4 o, int co) {
+    const size_t off = pix_off + co;
     if (a.bias) {
       const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
       o.x += bv.x;
@@ -153,6 +170,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     o.z = apply_act(o.z, a.act);
     o.w = apply_act(o.w, a.act);
     *reinterpret_cast<float4*>(a.out + off) = o;
+  };
+
+  if (SPLIT == 1) {
+    // lane (p,h) holds channels (r&3) + 8*(r>>2) + 4h of its pixel: four float4 stores
+    if (in_image) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        finish(make_float4(acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]), cb * 32 + q * 8 + half * 4);
+    }
+  } else {
+    // ---- cross-wave K reduction through LDS, epilogue by the first four waves -------------------
+    __syncthreads();  // every wave is done reading its patch
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave < 4) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = wave * 4 + j;
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) sum += lds[u * TILE_FLOATS + r * 64 + lane];
+        v[j] = sum;
+      }
+      if (in_image) finish(make_float4(v[0], v[1], v[2], v[3]), cb * 32 + wave * 8 + half * 4);
+    }
   }
 }
 
@@ -343,12 +387,28 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
   const long blocks = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
   DT_REQUIRE(blocks < 2147483647L, "dt_conv2d_f32: grid too large");
   hipStream_t st = to_stream(s);
+  // K-split policy: enough output blocks to fill 1024 SIMDs several times over -> no split;
+  // otherwise split K over 4 or 16 waves so that small layers still occupy the chip.
+  const long k_steps = (long)a.groups * d->ksize * d->ksize;  // groups x taps per block
+  int split = 4;
+  if (blocks >= 4096 || k_steps <= 16) split = 1;
+  else if (blocks * 4 < 2048 && a.groups >= 32) split = 16;
+#define DT_LAUNCH_CONV(KS_, ST_)                                                                                   \
+  do {                                                                                                             \
+    if (split == 1)                                                                                                \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 1>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, a); \
+    else if (split == 4)                                                                                           \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a);             \
+    else                                                                                                           \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, a);           \
+  } while (0)
   if (d->ksize == 3 && d->stride == 1)
-    hipLaunchKernelGGL((conv_mfma_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    DT_LAUNCH_CONV(3, 1);
   else if (d->ksize == 3 && d->stride == 2)
-    hipLaunchKernelGGL((conv_mfma_kernel<3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    DT_LAUNCH_CONV(3, 2);
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    DT_LAUNCH_CONV(1, 1);
+#undef DT_LAUNCH_CONV
   return check_launch("dt_conv2d_f32");
 }
 

@@ -23,6 +23,8 @@
 // contracted once per task into `accp` and reused as the initial layer-1 accumulator of every
 // plane.  One 256-thread workgroup per CU keeps the plane-dependent layer-1 weights, layer-2
 // weights and the tail (b2, W3, b3) resident in LDS (152.6 KB for K=7).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "cv_geometry.hpp"
 
@@ -36,6 +38,7 @@ constexpr int kPixFixed = 10;      // 8 cur-feature steps + (ray.x|ray.y) + (ray
 constexpr int kStepFloats = 256;   // [2 halves][32 lanes][4 blocks]
 constexpr int kW2Steps = 64;
 constexpr int kTailFloats = 260;   // b2r[128], w3r[128], b3, pad[3]
+constexpr int kHintFloats = 220;   // hint MLP (217 floats) staged in LDS behind the tail
 constexpr int kMaxSrcMfma = 7;     // LDS budget: 12*K + 64 + ~1 KB <= 160 KB
 
 __host__ __device__ inline int mlp_w1dyn_floats(int K) { return K * kStepsPerView * kStepFloats; }
@@ -100,6 +103,28 @@ __device__ __forceinline__ void issue_view(ViewData& v, const float* __restrict_
   v.ang = cos_sim3(crx, cry, crz, sx, sy, sz);
 }
 
+// hint MLP evaluated from LDS with a rolled outer loop: fully unrolled, the 217 weight reads are
+// all issued up front and spill ~100 registers in the two-waves-per-SIMD variant.
+__device__ __forceinline__ float hint_mlp_eval_lds(const float* hm, float s, float hint, float hw) {
+  float a[12];
+#pragma unroll
+  for (int m = 0; m < 12; ++m)
+    a[m] = lrelu(hm[m * 3 + 0] * s + hm[m * 3 + 1] * hint + hm[m * 3 + 2] * hw + hm[36 + m], 0.01f);
+  float out = hm[216];
+#pragma unroll 1
+  for (int n = 0; n < 12; ++n) {
+    const float4 r0 = *reinterpret_cast<const float4*>(hm + 48 + n * 12);
+    const float4 r1 = *reinterpret_cast<const float4*>(hm + 48 + n * 12 + 4);
+    const float4 r2 = *reinterpret_cast<const float4*>(hm + 48 + n * 12 + 8);
+    float acc = hm[192 + n];
+    acc += r0.x * a[0] + r0.y * a[1] + r0.z * a[2] + r0.w * a[3];
+    acc += r1.x * a[4] + r1.y * a[5] + r1.z * a[6] + r1.w * a[7];
+    acc += r2.x * a[8] + r2.y * a[9] + r2.z * a[10] + r2.w * a[11];
+    out += hm[204 + n] * lrelu(acc, 0.01f);
+  }
+  return out;
+}
+
 #define DT_MFMA4(ACC, A4, BVAL)                                                   \
   do {                                                                            \
     ACC[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A4).x, (BVAL), ACC[0], 0, 0, 0); \
@@ -108,8 +133,13 @@ __device__ __forceinline__ void issue_view(ViewData& v, const float* __restrict_
     ACC[3] = __builtin_amdgcn_mfma_f32_32x32x2f32((A4).w, (BVAL), ACC[3], 0, 0, 0); \
   } while (0)
 
-template <bool HINT>
-__global__ __launch_bounds__(256, 1) void cv_mlp_mfma_kernel(const MlpArgs a) {
+// NWAVES = 4: one wave per SIMD, up to 512 registers, next view's gather prefetched by hand.
+// NWAVES = 8: two waves per SIMD (<= 256 registers each): the partner wave's MFMAs cover this
+//             wave's gather / VALU phases, so no manual prefetch; layer 2 runs in two passes of
+//             64 output features to halve its accumulator footprint.
+template <bool HINT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(const MlpArgs a) {
+  constexpr int NT = NWAVES * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int K = a.K, D = a.D, h = a.h, w = a.w;
   const int n_dyn = mlp_w1dyn_floats(K);
@@ -121,13 +151,15 @@ __global__ __launch_bounds__(256, 1) void cv_mlp_mfma_kernel(const MlpArgs a) {
   {
     const float4* g1 = reinterpret_cast<const float4*>(a.w1dyn);
     float4* l1 = reinterpret_cast<float4*>(lds_w1);
-    for (int i = threadIdx.x; i < n_dyn / 4; i += 256) l1[i] = g1[i];
+    for (int i = threadIdx.x; i < n_dyn / 4; i += NT) l1[i] = g1[i];
     const float4* g2 = reinterpret_cast<const float4*>(a.w2p);
     float4* l2 = reinterpret_cast<float4*>(lds_w2);
-    for (int i = threadIdx.x; i < kW2Floats / 4; i += 256) l2[i] = g2[i];
+    for (int i = threadIdx.x; i < kW2Floats / 4; i += NT) l2[i] = g2[i];
     const float4* g3 = reinterpret_cast<const float4*>(a.tail);
     float4* l3 = reinterpret_cast<float4*>(lds_tail);
-    for (int i = threadIdx.x; i < kTailFloats / 4; i += 256) l3[i] = g3[i];
+    for (int i = threadIdx.x; i < kTailFloats / 4; i += NT) l3[i] = g3[i];
+    if (HINT)
+      for (int i = threadIdx.x; i < 217; i += NT) lds_tail[kTailFloats + i] = a.hint_mlp[i];
   }
   __syncthreads();
 
@@ -137,10 +169,10 @@ __global__ __launch_bounds__(256, 1) void cv_mlp_mfma_kernel(const MlpArgs a) {
   const size_t hw = (size_t)h * w;
   const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
   const int lane_off = (half * 32 + pl) * 4;  // float offset of this lane inside a step block
-  const int waves_total = gridDim.x * 4;
+  const int waves_total = gridDim.x * NWAVES;
   const float b3 = lds_tail[256];
 
-  for (int task = blockIdx.x * 4 + wave; task < a.num_tasks; task += waves_total) {
+  for (int task = blockIdx.x * NWAVES + wave; task < a.num_tasks; task += waves_total) {
     const int tile = task % a.num_tiles;
     const int g = (task / a.num_tiles) % a.num_groups;
     const int b = task / (a.num_tiles * a.num_groups);
@@ -208,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void cv_mlp_mfma_kernel(const MlpArgs a) {
 
     // ---- planes -------------------------------------------------------------------------
     ViewData nxt;
-    {
+    if (NWAVES == 4) {
       const float depth = p[kCvPlanes + d0];
       issue_view(nxt, p + cv_view_off(D, 0), src_b, depth * rx, depth * ry, depth * rz, crx, cry, crz, h, w,
                  inv_w, inv_h, half);
@@ -221,9 +253,10 @@ __global__ __launch_bounds__(256, 1) void cv_mlp_mfma_kernel(const MlpArgs a) {
       for (int i = 0; i < 4; ++i) acc1[i] = accp[i];
 
       for (int k = 0; k < K; ++k) {
-        const ViewData v = nxt;
-        // prefetch the next (plane, view) before this view's MFMA block
-        {
+        ViewData v;
+        if (NWAVES == 4) {
+          v = nxt;
+          // prefetch the next (plane, view) before this view's MFMA block
           int nk = k + 1, nd = d;
           if (nk == K) {
             nk = 0;
@@ -234,6 +267,9 @@ __global__ __launch_bounds__(256, 1) void cv_mlp_mfma_kernel(const MlpArgs a) {
             issue_view(nxt, p + cv_view_off(D, nk), src_b + (size_t)nk * hw * kF, ndepth * rx, ndepth * ry,
                        ndepth * rz, crx, cry, crz, h, w, inv_w, inv_h, half);
           }
+        } else {
+          issue_view(v, p + cv_view_off(D, k), src_b + (size_t)k * hw * kF, X, Y, Z, crx, cry, crz, h, w, inv_w, inv_h,
+                     half);
         }
         float f[8];
         f[0] = v.t00a.x * v.w00 + v.t01a.x * v.w01 + v.t10a.x * v.w10 + v.t11a.x * v.w11;
@@ -284,43 +320,74 @@ __global__ __launch_bounds__(256, 1) void cv_mlp_mfma_kernel(const MlpArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[i][r] = fmaxf(acc1[i][r], 0.01f * acc1[i][r]);
 
-      // ---- layer 2: acc2 = b2 + W2 h1 --------------------------------------------------------
-      f32x16 acc2[4];
-      {
-        const float* bl = lds_tail + half * 64;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc2[i][r] = bl[i * 16 + r];
-      }
-      {
-        const float4* wl = reinterpret_cast<const float4*>(lds_w2 + lane_off);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float4 a4 = wl[(i * 16 + r) * (kStepFloats / 4)];
-            DT_MFMA4(acc2, a4, acc1[i][r]);
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-          }
-      }
-      // ---- layer 3 + cross-half sum ---------------------------------------------------------
+      // ---- layer 2: acc2 = b2 + W2 h1, layer 3: s = W3 . lrelu(acc2) ----------------------------
       float s = 0.f;
-      {
-        const float* wl = lds_tail + 128 + half * 64;
+      if (NWAVES == 4) {
+        f32x16 acc2[4];
+        {
+          const float* bl = lds_tail + half * 64;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v2 = acc2[i][r];
-            s += wl[i * 16 + r] * fmaxf(v2, 0.01f * v2);
-          }
+            for (int r = 0; r < 16; ++r) acc2[i][r] = bl[i * 16 + r];
+        }
+        {
+          const float4* wl = reinterpret_cast<const float4*>(lds_w2 + lane_off);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float4 a4 = wl[(i * 16 + r) * (kStepFloats / 4)];
+              DT_MFMA4(acc2, a4, acc1[i][r]);
+              if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {
+          const float* wl = lds_tail + 128 + half * 64;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v2 = acc2[i][r];
+              s += wl[i * 16 + r] * fmaxf(v2, 0.01f * v2);
+            }
+        }
+      } else {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          f32x16 acc2[2];
+          const float* bl = lds_tail + half * 64 + pass * 32;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][r] = bl[i * 16 + r];
+          const float2* wl = reinterpret_cast<const float2*>(lds_w2 + lane_off + pass * 2);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float2 a2 = wl[(i * 16 + r) * (kStepFloats / 2)];
+              acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, acc1[i][r], acc2[0], 0, 0, 0);
+              acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, acc1[i][r], acc2[1], 0, 0, 0);
+              if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+          const float* w3 = lds_tail + 128 + half * 64 + pass * 32;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v2 = acc2[i][r];
+              s += w3[i * 16 + r] * fmaxf(v2, 0.01f * v2);
+            }
+        }
       }
       s += __shfl_xor(s, 32, 64);
       s += b3;
       if (HINT) {
         const float hint = hmask ? fabsf(hdepth - depth) : -1.f;
-        s = hint_mlp_eval(a.hint_mlp, s, hint, hweight);
+        // keep the 217 weight reads inside the plane loop (hoisted, they cost > 100 spilled registers)
+        asm volatile("" ::: "memory");
+        s = hint_mlp_eval_lds(lds_tail + kTailFloats, s, hint, hweight);
       }
       if (live && half == 0) {
         if (a.out_nhwc)
@@ -333,6 +400,8 @@ __global__ __launch_bounds__(256, 1) void cv_mlp_mfma_kernel(const MlpArgs a) {
 }
 
 
+// waves per workgroup of the fused kernel (4 = one per SIMD, 8 = two per SIMD); DT_MLP_WAVES overrides
+static int g_mlp_waves = [] { const char* e = getenv("DT_MLP_WAVES"); return (e && e[0] == '4') ? 4 : 8; }();
 static int g_num_cus = 0;
 static int num_cus() {
   if (g_num_cus > 0) return g_num_cus;
@@ -378,7 +447,7 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
   const long hw = (long)h * w;
   a.num_tiles = (int)((hw + 31) / 32);
   const int cus = num_cus();
-  const long slots = (long)cus * 4;  // one wave per SIMD
+  const long slots = (long)cus * g_mlp_waves;  // resident waves
   // planes per task: minimise (rounds of tasks over the wave slots) x (MFMAs per task)
   const long per_plane = (long)num_src * kStepsPerView * 4 + kW2Steps * 4;
   const long per_task = (long)(kPixFixed + 2 * num_src) * 4;
@@ -394,18 +463,25 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
   a.PG = best_pg;
   a.num_groups = (num_planes + best_pg - 1) / best_pg;
   a.num_tasks = a.num_groups * a.num_tiles * batch;
-  const int blocks = (int)((a.num_tasks + 3) / 4 < cus ? (a.num_tasks + 3) / 4 : cus);
-  const size_t lds_bytes = (size_t)(mlp_w1dyn_floats(num_src) + kW2Floats + kTailFloats) * sizeof(float);
-  hipError_t e;
+  const size_t lds_bytes = (size_t)(mlp_w1dyn_floats(num_src) + kW2Floats + kTailFloats + kHintFloats) * sizeof(float);
+  const int nw = g_mlp_waves;
+  const int blocks = (int)((a.num_tasks + nw - 1) / nw < cus ? (a.num_tasks + nw - 1) / nw : cus);
+#define DT_LAUNCH_MLP(HINT_, NW_)                                                                                  \
+  do {                                                                                                             \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cv_mlp_mfma_kernel<HINT_, NW_>),               \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                \
+    if (e != hipSuccess) {                                                                                         \
+      (void)hipGetLastError();                                                                                     \
+      return fail("dt_cv_mlp_hint_f32: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));          \
+    }                                                                                                              \
+    hipLaunchKernelGGL((cv_mlp_mfma_kernel<HINT_, NW_>), dim3(blocks), dim3(NW_ * 64), lds_bytes, to_stream(s), a); \
+  } while (0)
   if (hint_mlp) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cv_mlp_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail("dt_cv_mlp_hint_f32: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); }
-    hipLaunchKernelGGL(cv_mlp_mfma_kernel<true>, dim3(blocks), dim3(256), lds_bytes, to_stream(s), a);
+    if (nw == 8) DT_LAUNCH_MLP(true, 8); else DT_LAUNCH_MLP(true, 4);
   } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cv_mlp_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail("dt_cv_mlp_hint_f32: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e)); }
-    hipLaunchKernelGGL(cv_mlp_mfma_kernel<false>, dim3(blocks), dim3(256), lds_bytes, to_stream(s), a);
+    if (nw == 8) DT_LAUNCH_MLP(false, 8); else DT_LAUNCH_MLP(false, 4);
   }
+#undef DT_LAUNCH_MLP
   return check_launch("dt_cv_mlp_hint_f32");
 }
 

@@ -33,6 +33,12 @@ CONV_CASES = [
     ("cat2_up", 2, [(32, True), (24, False)], 12, 16, 32, 3, 1, 2, False),
     ("cat3", 1, [(64, False), (64, False), (64, False)], 8, 12, 64, 3, 1, 1, True),
     ("k1_cat", 1, [(8, False), (8, True)], 6, 10, 32, 1, 1, 0, False),
+    # deep-K / few-block layers take the 16-way K-split path; many-block layers the no-split path
+    ("k3s1_split16", 1, [(256, False)], 8, 8, 32, 3, 1, 1, True),
+    ("k3s2_split16", 1, [(192, False), (64, False)], 16, 16, 64, 3, 2, 2, False),
+    ("k1_split16", 1, [(512, False)], 7, 9, 32, 1, 1, 0, False),
+    ("k3s1_nosplit", 2, [(16, False)], 128, 160, 64, 3, 1, 1, True),
+    ("k3s2_nosplit", 1, [(8, False)], 260, 252, 32, 3, 2, 0, False),
 ]
 
 
