@@ -25,6 +25,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # and an add of two different reference ops into one FMA would drop a rounding, so contraction is
 # off for the whole file (hipcc's default is fast-honor-pragmas).
 EXTRA_FLAGS = {"tsdf.hip": ["-ffp-contract=off"]}
+# experiment hook: extra -D flags for every file (e.g. DT_EXTRA_CFLAGS="-DDT_MLP_PRIO=1")
+FLAGS += os.environ.get("DT_EXTRA_CFLAGS", "").split()
 
 
 def _sources():

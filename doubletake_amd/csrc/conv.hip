@@ -48,10 +48,10 @@ constexpr int kPH = 4, kPW = 8;  // output patch of one MFMA pixel block
 //   1  : every wave owns a whole block (4 blocks per 256-thread workgroup), no reduction;
 //        used when the layer has enough blocks to fill the chip on its own
 //   4  : one block per 256-thread workgroup, 4-way K split, LDS reduction
-//   16 : one block per 1024-thread workgroup, 16-way K split (the 15x20 / 30x40 levels)
+//   8  : one block per 512-thread workgroup, 8-way K split (the 15x20 / 30x40 levels)
 template <int KS, int ST, int SPLIT>
-__global__ __launch_bounds__(SPLIT == 16 ? 1024 : 256) void conv_mfma_kernel(const ConvArgs a) {
-  constexpr int NW = (SPLIT == 16) ? 16 : 4;
+__global__ __launch_bounds__(SPLIT == 8 ? 512 : 256) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int NW = (SPLIT == 8) ? 8 : 4;
   constexpr int IH = (kPH - 1) * ST + KS, IW = (kPW - 1) * ST + KS;
   constexpr int NPIX = IH * IW;
   constexpr int NLOAD = (NPIX + 31) / 32;  // float4 staging loads per lane and group
@@ -80,9 +80,15 @@ __global__ __launch_bounds__(SPLIT == 16 ? 1024 : 256) void conv_mfma_kernel(con
   const int iy0 = ty * kPH * ST - PAD, ix0 = tx * kPW * ST - PAD;
   float* tile = lds + wave * TILE_FLOATS;
 
-  f32x16 acc;
+  // Four independent accumulators (one per k-slot of the float4 operands).  A chain of dependent
+  // v_mfma_f32_32x32x2_f32 on ONE accumulator issues at ~1/4 of the pipe rate on gfx950 (measured:
+  // SQ_VALU_MFMA_BUSY 25-55 % with one chain per wave), so the K sum is kept in four partial sums
+  // that are added in the epilogue.
+  f32x16 acc4[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
 
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
   const int g_first = (SPLIT == 1) ? 0 : wave;
@@ -139,12 +145,15 @@ __global__ __launch_bounds__(SPLIT == 16 ? 1024 : 256) void conv_mfma_kernel(con
     for (int t = 0; t < TAPS; ++t) {
       const int ky = t / KS, kx = t - ky * KS;
       const float4 b4 = *reinterpret_cast<const float4*>(tile + ((py * ST + ky) * IW + (px * ST + kx)) * 8 + half * 4);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].x, b4.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].y, b4.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].z, b4.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].w, b4.w, acc, 0, 0, 0);
+      acc4[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].x, b4.x, acc4[0], 0, 0, 0);
+      acc4[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].y, b4.y, acc4[1], 0, 0, 0);
+      acc4[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].z, b4.z, acc4[2], 0, 0, 0);
+      acc4[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].w, b4.w, acc4[3], 0, 0, 0);
     }
   }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
 
   const bool in_image = have_block && oy < a.h_out && ox < a.w_out;
   const size_t pix_off = (((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out;
@@ -388,11 +397,11 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
   DT_REQUIRE(blocks < 2147483647L, "dt_conv2d_f32: grid too large");
   hipStream_t st = to_stream(s);
   // K-split policy: enough output blocks to fill 1024 SIMDs several times over -> no split;
-  // otherwise split K over 4 or 16 waves so that small layers still occupy the chip.
+  // otherwise split K over 4 or 8 waves so that small layers still occupy the chip.
   const long k_steps = (long)a.groups * d->ksize * d->ksize;  // groups x taps per block
   int split = 4;
   if (blocks >= 4096 || k_steps <= 16) split = 1;
-  else if (blocks * 4 < 2048 && a.groups >= 32) split = 16;
+  else if (blocks * 4 < 2048 && a.groups >= 16) split = 8;
 #define DT_LAUNCH_CONV(KS_, ST_)                                                                                   \
   do {                                                                                                             \
     if (split == 1)                                                                                                \
@@ -400,7 +409,7 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
     else if (split == 4)                                                                                           \
       hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a);             \
     else                                                                                                           \
-      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, a);           \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 8>), dim3((unsigned)blocks), dim3(512), 0, st, a);             \
   } while (0)
   if (d->ksize == 3 && d->stride == 1)
     DT_LAUNCH_CONV(3, 1);

@@ -10,20 +10,27 @@
 
 namespace dt {
 
+// Read-only, wave-uniform parameter blocks are read through the constant address space so that the
+// compiler emits scalar loads (s_load_dword -> SGPR operands) even in kernels that also store
+// through unrelated global pointers.
+typedef const float __attribute__((address_space(4))) * cfloat_ptr;
+__device__ __forceinline__ cfloat_ptr as_const(const float* p) { return (cfloat_ptr)(uintptr_t)p; }
+
 struct ViewProj {
   float u, v, z;  // source pixel coords (pixel centres at +0.5) and z' = depth + eps
 };
 
 // cam ray r = invK3 @ (x+0.5, y+0.5, 1)
-__device__ __forceinline__ void pixel_ray(const float* __restrict__ invK3, int x, int y, float& rx,
-                                          float& ry, float& rz) {
+template <class PT>
+__device__ __forceinline__ void pixel_ray(PT invK3, int x, int y, float& rx, float& ry, float& rz) {
   const float px = (float)x + 0.5f, py = (float)y + 0.5f;
   rx = invK3[0] * px + invK3[1] * py + invK3[2];
   ry = invK3[3] * px + invK3[4] * py + invK3[5];
   rz = invK3[6] * px + invK3[7] * py + invK3[8];
 }
 
-__device__ __forceinline__ ViewProj project_view(const float* __restrict__ P, float X, float Y, float Z) {
+template <class PT>
+__device__ __forceinline__ ViewProj project_view(PT P, float X, float Y, float Z) {
   const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
   const float qy = P[4] * X + P[5] * Y + P[6] * Z + P[7];
   const float qz = P[8] * X + P[9] * Y + P[10] * Z + P[11];

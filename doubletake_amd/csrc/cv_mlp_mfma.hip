@@ -61,8 +61,8 @@ struct MlpArgs {
   int hint_h, hint_w2;
   int out_nhwc;
   int B, K, h, w, D;
-  int PG;                 // planes per task
-  int num_tiles, num_groups, num_tasks;
+  int num_tiles;          // 32-pixel tiles per batch element
+  long total_units;       // B * num_tiles * D (tile, plane) units, split evenly over the resident waves
 };
 
 // one source view's gathered taps + metadata, produced by issue_view(), consumed later
@@ -72,7 +72,7 @@ struct ViewData {
   float z, sx, sy, sz, ang;
 };
 
-__device__ __forceinline__ void issue_view(ViewData& v, const float* __restrict__ vp,
+__device__ __forceinline__ void issue_view(ViewData& v, cfloat_ptr vp,
                                            const float* __restrict__ src_view, float X, float Y, float Z,
                                            float crx, float cry, float crz, int h, int w, float inv_w,
                                            float inv_h, int half) {
@@ -95,12 +95,15 @@ __device__ __forceinline__ void issue_view(ViewData& v, const float* __restrict_
   v.w10 = t.w10;
   v.w11 = t.w11;
   v.z = q.z;
-  float sx = X - vp[12], sy = Y - vp[13], sz = Z - vp[14];
-  normalize3(sx, sy, sz);
-  v.sx = sx;
-  v.sy = sy;
-  v.sz = sz;
-  v.ang = cos_sim3(crx, cry, crz, sx, sy, sz);
+  // source ray = normalize(X - t_src); angle = cos between the two unit rays.  One v_rsq_f32
+  // instead of sqrt + divide, and the cosine of two unit vectors is their dot product (the
+  // reference's clamp_min(eps) on the norms is inactive): differences ~1e-7, far below tolerance.
+  const float sx = X - vp[12], sy = Y - vp[13], sz = Z - vp[14];
+  const float inv = rsqrtf(fmaxf(sx * sx + sy * sy + sz * sz, 1e-24f));
+  v.sx = sx * inv;
+  v.sy = sy * inv;
+  v.sz = sz * inv;
+  v.ang = crx * v.sx + cry * v.sy + crz * v.sz;
 }
 
 // hint MLP evaluated from LDS with a rolled outer loop: fully unrolled, the 217 weight reads are
@@ -133,10 +136,11 @@ __device__ __forceinline__ float hint_mlp_eval_lds(const float* hm, float s, flo
     ACC[3] = __builtin_amdgcn_mfma_f32_32x32x2f32((A4).w, (BVAL), ACC[3], 0, 0, 0); \
   } while (0)
 
-// NWAVES = 4: one wave per SIMD, up to 512 registers, next view's gather prefetched by hand.
-// NWAVES = 8: two waves per SIMD (<= 256 registers each): the partner wave's MFMAs cover this
-//             wave's gather / VALU phases, so no manual prefetch; layer 2 runs in two passes of
-//             64 output features to halve its accumulator footprint.
+// NWAVES = 4: one wave per SIMD, up to 512 registers, four accumulator chains in both layers.
+// NWAVES = 8: two waves per SIMD (<= 256 registers each); layer 2 runs in two passes of 64 output
+//             features (two accumulator chains per wave) to fit the register budget.
+// A chain of dependent v_mfma_f32_32x32x2_f32 issues at ~1/4 of the pipe rate, so >= 4 independent
+// accumulators must be in flight per SIMD to keep the matrix pipe full.
 template <bool HINT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(const MlpArgs a) {
   constexpr int NT = NWAVES * 64;
@@ -169,15 +173,32 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   const size_t hw = (size_t)h * w;
   const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
   const int lane_off = (half * 32 + pl) * 4;  // float offset of this lane inside a step block
-  const int waves_total = gridDim.x * NWAVES;
+  const long waves_total = (long)gridDim.x * NWAVES;
   const float b3 = lds_tail[256];
+#if defined(DT_MLP_PRIO)
+  // static priority for the younger half of a two-waves-per-SIMD workgroup: breaks the lock-step
+  // in which both waves of a SIMD reach their gather/VALU phase together and leave the matrix pipe idle
+  if (NWAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(DT_MLP_PRIO);
+#endif
 
-  for (int task = blockIdx.x * NWAVES + wave; task < a.num_tasks; task += waves_total) {
-    const int tile = task % a.num_tiles;
-    const int g = (task / a.num_tiles) % a.num_groups;
-    const int b = task / (a.num_tiles * a.num_groups);
-    const int d0 = g * a.PG, d1 = min(d0 + a.PG, D);
-    const float* p = a.params + (size_t)b * cv_params_floats(D, K);
+  // Balanced static partition: the (batch, tile, plane) units are flattened (plane fastest) and every
+  // resident wave takes one contiguous span of floor/ceil(total / waves) units, i.e. one or two
+  // partial tiles.  (With a fixed planes-per-task granularity the B=1 case left up to 25 % of the
+  // waves one task short of the others.)
+  const long wid = (long)blockIdx.x * NWAVES + wave;
+  long u = wid * a.total_units / waves_total;
+  const long u_end = (wid + 1) * a.total_units / waves_total;
+  while (u < u_end) {
+    // integer division runs on the VALU, which makes its results "divergent" to the compiler and
+    // turns every per-view parameter read below into a waited vector load; readfirstlane restores
+    // wave-uniformity so they become scalar loads (SGPR operands, scalar cache).
+    const long tile_global = u / D;
+    const int d0 = __builtin_amdgcn_readfirstlane((int)(u - tile_global * D));
+    const int d1 = __builtin_amdgcn_readfirstlane((int)min((long)D, d0 + (u_end - u)));
+    const int tile = __builtin_amdgcn_readfirstlane((int)(tile_global % a.num_tiles));
+    const int b = __builtin_amdgcn_readfirstlane((int)(tile_global / a.num_tiles));
+    u += d1 - d0;
+    const cfloat_ptr p = as_const(a.params + (size_t)b * cv_params_floats(D, K));
     const float* src_b = a.src + (size_t)b * K * hw * kF;
 
     const size_t pixi = (size_t)tile * 32 + pl;
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         DT_MFMA4(accp, a4, bv);
       }
       for (int k = 0; k < K; ++k) {
-        const float* vp = p + cv_view_off(D, k);
+        const cfloat_ptr vp = p + cv_view_off(D, k);
         const float4 a4 = wp[(kPixFixed + 2 * k) * (kStepFloats / 4)];
         const float bv = half ? vp[16] : vp[15];
         DT_MFMA4(accp, a4, bv);
@@ -239,38 +260,21 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
     }
 
     // ---- planes -------------------------------------------------------------------------
-    ViewData nxt;
-    if (NWAVES == 4) {
+    // Software pipeline with ONE ViewData: consume view k into f[] / scalars, re-issue the gathers
+    // of the next (plane, view) into the same registers, then run view k's 48 MFMAs while they fly.
+    ViewData v;
+    {
       const float depth = p[kCvPlanes + d0];
-      issue_view(nxt, p + cv_view_off(D, 0), src_b, depth * rx, depth * ry, depth * rz, crx, cry, crz, h, w,
-                 inv_w, inv_h, half);
+      issue_view(v, p + cv_view_off(D, 0), src_b, depth * rx, depth * ry, depth * rz, crx, cry, crz, h, w, inv_w,
+                 inv_h, half);
     }
     for (int d = d0; d < d1; ++d) {
       const float depth = p[kCvPlanes + d];
-      const float X = depth * rx, Y = depth * ry, Z = depth * rz;
       f32x16 acc1[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc1[i] = accp[i];
 
       for (int k = 0; k < K; ++k) {
-        ViewData v;
-        if (NWAVES == 4) {
-          v = nxt;
-          // prefetch the next (plane, view) before this view's MFMA block
-          int nk = k + 1, nd = d;
-          if (nk == K) {
-            nk = 0;
-            nd = d + 1;
-          }
-          if (nd < d1) {
-            const float ndepth = p[kCvPlanes + nd];
-            issue_view(nxt, p + cv_view_off(D, nk), src_b + (size_t)nk * hw * kF, ndepth * rx, ndepth * ry,
-                       ndepth * rz, crx, cry, crz, h, w, inv_w, inv_h, half);
-          }
-        } else {
-          issue_view(v, p + cv_view_off(D, k), src_b + (size_t)k * hw * kF, X, Y, Z, crx, cry, crz, h, w, inv_w, inv_h,
-                     half);
-        }
         float f[8];
         f[0] = v.t00a.x * v.w00 + v.t01a.x * v.w01 + v.t10a.x * v.w10 + v.t11a.x * v.w11;
         f[1] = v.t00a.y * v.w00 + v.t01a.y * v.w01 + v.t10a.y * v.w10 + v.t11a.y * v.w11;
@@ -280,11 +284,26 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         f[5] = v.t00b.y * v.w00 + v.t01b.y * v.w01 + v.t10b.y * v.w10 + v.t11b.y * v.w11;
         f[6] = v.t00b.z * v.w00 + v.t01b.z * v.w01 + v.t10b.z * v.w10 + v.t11b.z * v.w11;
         f[7] = v.t00b.w * v.w00 + v.t01b.w * v.w01 + v.t10b.w * v.w10 + v.t11b.w * v.w11;
+        const float vz = v.z, vang = v.ang, vsx = v.sx, vsy = v.sy, vsz = v.sz;
+        {
+          // branch-free: the loop body stays ONE basic block, so the scheduler can place the next
+          // view's projection / address / gather instructions between this view's MFMAs.  The
+          // very last prefetch of a task re-reads its final view (harmless).
+          int nk = k + 1, nd = d;
+          if (nk == K) {
+            nk = 0;
+            nd = d + 1;
+          }
+          nd = min(nd, d1 - 1);
+          const float ndepth = p[kCvPlanes + nd];
+          issue_view(v, p + cv_view_off(D, nk), src_b + (size_t)nk * hw * kF, ndepth * rx, ndepth * ry, ndepth * rz, crx,
+                     cry, crz, h, w, inv_w, inv_h, half);
+        }
         float dotp = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) dotp += f[j] * cur8[j];
         const float dot = dotp + __shfl_xor(dotp, 32, 64);
-        const float m = (v.z > 0.f) ? 1.f : 0.f;
+        const float m = (vz > 0.f) ? 1.f : 0.f;
 
         const float4* wl = reinterpret_cast<const float4*>(lds_w1 + (size_t)k * kStepsPerView * kStepFloats + lane_off);
 #pragma unroll
@@ -294,22 +313,22 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         }
         {
           const float4 a4 = wl[8 * (kStepFloats / 4)];
-          const float bv = half ? v.z : m;
+          const float bv = half ? vz : m;
           DT_MFMA4(acc1, a4, bv);
         }
         {
           const float4 a4 = wl[9 * (kStepFloats / 4)];
-          const float bv = half ? v.ang : dot * m;
+          const float bv = half ? vang : dot * m;
           DT_MFMA4(acc1, a4, bv);
         }
         {
           const float4 a4 = wl[10 * (kStepFloats / 4)];
-          const float bv = half ? v.sy : v.sx;
+          const float bv = half ? vsy : vsx;
           DT_MFMA4(acc1, a4, bv);
         }
         {
           const float4 a4 = wl[11 * (kStepFloats / 4)];
-          const float bv = half ? ((k == 0) ? depth : 0.f) : v.sz;
+          const float bv = half ? ((k == 0) ? depth : 0.f) : vsz;
           DT_MFMA4(acc1, a4, bv);
         }
       }
@@ -447,25 +466,11 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
   const long hw = (long)h * w;
   a.num_tiles = (int)((hw + 31) / 32);
   const int cus = num_cus();
-  const long slots = (long)cus * g_mlp_waves;  // resident waves
-  // planes per task: minimise (rounds of tasks over the wave slots) x (MFMAs per task)
-  const long per_plane = (long)num_src * kStepsPerView * 4 + kW2Steps * 4;
-  const long per_task = (long)(kPixFixed + 2 * num_src) * 4;
-  int best_pg = num_planes;
-  long best_cost = -1;
-  for (int pg = 1; pg <= num_planes; ++pg) {
-    const long groups = (num_planes + pg - 1) / pg;
-    const long tasks = groups * a.num_tiles * batch;
-    const long rounds = (tasks + slots - 1) / slots;
-    const long cost = rounds * (per_task + (long)pg * per_plane);
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_pg = pg; }
-  }
-  a.PG = best_pg;
-  a.num_groups = (num_planes + best_pg - 1) / best_pg;
-  a.num_tasks = a.num_groups * a.num_tiles * batch;
+  a.total_units = (long)batch * a.num_tiles * num_planes;
   const size_t lds_bytes = (size_t)(mlp_w1dyn_floats(num_src) + kW2Floats + kTailFloats + kHintFloats) * sizeof(float);
   const int nw = g_mlp_waves;
-  const int blocks = (int)((a.num_tasks + nw - 1) / nw < cus ? (a.num_tasks + nw - 1) / nw : cus);
+  const long want = (a.total_units + nw - 1) / nw;  // at least one unit per wave
+  const int blocks = (int)(want < cus ? want : cus);
 #define DT_LAUNCH_MLP(HINT_, NW_)                                                                                  \
   do {                                                                                                             \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cv_mlp_mfma_kernel<HINT_, NW_>),               \
