@@ -44,6 +44,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 constexpr int kPH = 4, kPW = 8;  // output patch of one MFMA pixel block
 
+// element offset of input pixel (iy, ix) of image n inside one NHWC source (nearest-upsampled when
+// `up`), plus this lane's 4-channel half of the 8-channel group; -1 = zero padding
+__device__ __forceinline__ int pixel_offset(bool inside, int n, int iy, int ix, int h_in, int w_in, int up, int cs,
+                                            int lane) {
+  const int hs = up ? (h_in >> 1) : h_in, ws = up ? (w_in >> 1) : w_in;
+  const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
+  return inside ? ((n * hs + sy) * ws + sx) * cs + (lane & 1) * 4 : -1;
+}
+
 // SPLIT = number of waves that share one 32-channel x 32-pixel output block by splitting K:
 //   1  : every wave owns a whole block (4 blocks per 256-thread workgroup), no reduction;
 //        used when the layer has enough blocks to fill the chip on its own
@@ -80,80 +89,96 @@ __global__ __launch_bounds__(SPLIT == 8 ? 512 : 256) void conv_mfma_kernel(const
   const int iy0 = ty * kPH * ST - PAD, ix0 = tx * kPW * ST - PAD;
   float* tile = lds + wave * TILE_FLOATS;
 
-  // Four independent accumulators (one per k-slot of the float4 operands).  A chain of dependent
-  // v_mfma_f32_32x32x2_f32 on ONE accumulator issues at ~1/4 of the pipe rate on gfx950 (measured:
-  // SQ_VALU_MFMA_BUSY 25-55 % with one chain per wave), so the K sum is kept in four partial sums
-  // that are added in the epilogue.
-  f32x16 acc4[4];
+  // one accumulator chain per wave is enough: dependent v_mfma_f32_32x32x2_f32 issue back to back
+  // (scripts/mfma_chain_bench.hip: 92 % of peak from a single chain, one wave per SIMD)
+  f32x16 acc;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
   const int g_first = (SPLIT == 1) ? 0 : wave;
   const int g_step = (SPLIT == 1) ? 1 : SPLIT;
 
-  float4 patch[NLOAD];
-  float4 wnext[TAPS];
-
-  // issue the global loads of one 8-channel group: its input patch and its 9 (or 1) weight fragments
-  auto prefetch = [&](int g) {
-    int s = 0, gl = g;
-    while (s + 1 < a.nsrc && gl >= (a.c[s] >> 3)) {
-      gl -= a.c[s] >> 3;
-      ++s;
-    }
-    const float* sp = a.src[s];
-    const int cs = a.c[s], up = a.up[s];
-    const int hs = up ? (a.h_in >> 1) : a.h_in, ws = up ? (a.w_in >> 1) : a.w_in;
+  // ---- per-lane, group-invariant addressing (hoisted out of the K loop) ----------------------------
+  // element offset of each staged pixel inside each source (or -1: zero padding / outside the patch)
+  int poff0[NLOAD], poff1[NLOAD], poff2[NLOAD];
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-      const int idx = (lane >> 1) + it * 32;
-      const int ly = idx / IW, lx = idx - ly * IW;
-      const int iy = iy0 + ly, ix = ix0 + lx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < NPIX && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) {
-        const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
-        v = *reinterpret_cast<const float4*>(sp + (((size_t)n * hs + sy) * ws + sx) * cs + gl * 8 + (lane & 1) * 4);
-      }
-      patch[it] = v;
-    }
-    const float4* wg = wp4 + ((size_t)(cb * a.groups + g) * TAPS * 2 + half) * 32 + p;
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) wnext[t] = wg[(size_t)t * 64];
-  };
-
-  if (g_first < a.groups) prefetch(g_first);
-  for (int g = g_first; g < a.groups; g += g_step) {
-    // ---- publish the prefetched patch to this wave's LDS tile ---------------------------------
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-      const int idx = (lane >> 1) + it * 32;
-      if (idx < NPIX) *reinterpret_cast<float4*>(tile + idx * 8 + (lane & 1) * 4) = patch[it];
-    }
-    float4 wcur[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) wcur[t] = wnext[t];
-    // ---- next group's loads fly while this group's MFMAs run ------------------------------------
-    if (g + g_step < a.groups) prefetch(g + g_step);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int ky = t / KS, kx = t - ky * KS;
-      const float4 b4 = *reinterpret_cast<const float4*>(tile + ((py * ST + ky) * IW + (px * ST + kx)) * 8 + half * 4);
-      acc4[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].x, b4.x, acc4[0], 0, 0, 0);
-      acc4[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].y, b4.y, acc4[1], 0, 0, 0);
-      acc4[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].z, b4.z, acc4[2], 0, 0, 0);
-      acc4[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[t].w, b4.w, acc4[3], 0, 0, 0);
-    }
+  for (int it = 0; it < NLOAD; ++it) {
+    const int idx = (lane >> 1) + it * 32;
+    const int ly = idx / IW, lx = idx - ly * IW;
+    const int iy = iy0 + ly, ix = ix0 + lx;
+    const bool inside = idx < NPIX && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+    poff0[it] = pixel_offset(inside, n, iy, ix, a.h_in, a.w_in, a.up[0], a.c[0], lane);
+    poff1[it] = pixel_offset(inside && a.nsrc > 1, n, iy, ix, a.h_in, a.w_in, a.up[1], a.c[1], lane);
+    poff2[it] = pixel_offset(inside && a.nsrc > 2, n, iy, ix, a.h_in, a.w_in, a.up[2], a.c[2], lane);
   }
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
+  const int ng0 = a.c[0] >> 3, ng1 = a.c[1] >> 3;
+  const float4* wbase = wp4 + ((size_t)cb * a.groups * TAPS * 2 + half) * 32 + p;
+
+  float4 patch[NLOAD];
+
+  // (macros, not lambdas: arrays captured or passed by reference end up in scratch memory)
+  // issue the global loads of one 8-channel group's input patch
+#define DT_PREFETCH_PATCH(G)                                                                         \
+  do {                                                                                               \
+    const int g_ = (G);                                                                              \
+    const int sidx = (g_ < ng0) ? 0 : ((g_ < ng0 + ng1) ? 1 : 2);                                    \
+    const int gl = (sidx == 0) ? g_ : ((sidx == 1) ? g_ - ng0 : g_ - ng0 - ng1);                     \
+    const float* sp = ((sidx == 0) ? src0 : ((sidx == 1) ? src1 : src2)) + gl * 8;                   \
+    _Pragma("unroll") for (int it = 0; it < NLOAD; ++it) {                                           \
+      const int off = (sidx == 0) ? poff0[it] : ((sidx == 1) ? poff1[it] : poff2[it]);               \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+      if (off >= 0) v = *reinterpret_cast<const float4*>(sp + off);                                  \
+      patch[it] = v;                                                                                 \
+    }                                                                                                \
+  } while (0)
+#define DT_LOAD_WEIGHTS(WREG, G)                                                                     \
+  do {                                                                                               \
+    const float4* wg = wbase + (size_t)(G) * (TAPS * 64);                                            \
+    _Pragma("unroll") for (int t = 0; t < TAPS; ++t) WREG[t] = wg[(size_t)t * 64];                   \
+  } while (0)
+  // one K step: publish the prefetched patch, start the next group's loads, run this group's MFMAs
+#define DT_K_STEP(WCUR, WNXT, G)                                                                     \
+  do {                                                                                               \
+    __builtin_amdgcn_wave_barrier();                                                                 \
+    _Pragma("unroll") for (int it = 0; it < NLOAD; ++it) {                                           \
+      const int idx = (lane >> 1) + it * 32;                                                         \
+      if (idx < NPIX) *reinterpret_cast<float4*>(tile + idx * 8 + (lane & 1) * 4) = patch[it];       \
+    }                                                                                                \
+    if ((G) + g_step < a.groups) {                                                                   \
+      DT_PREFETCH_PATCH((G) + g_step);                                                               \
+      DT_LOAD_WEIGHTS(WNXT, (G) + g_step);                                                           \
+    }                                                                                                \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                           \
+    __builtin_amdgcn_wave_barrier();                                                                 \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                           \
+    _Pragma("unroll") for (int t = 0; t < TAPS; ++t) {                                               \
+      const int ky = t / KS, kx = t - ky * KS;                                                       \
+      const float4 b4 =                                                                              \
+          *reinterpret_cast<const float4*>(tile + ((py * ST + ky) * IW + (px * ST + kx)) * 8 + half * 4); \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WCUR[t].x, b4.x, acc, 0, 0, 0);                     \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WCUR[t].y, b4.y, acc, 0, 0, 0);                     \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WCUR[t].z, b4.z, acc, 0, 0, 0);                     \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WCUR[t].w, b4.w, acc, 0, 0, 0);                     \
+    }                                                                                                \
+  } while (0)
+
+  const float* src0 = a.src[0];
+  const float* src1 = a.src[1];
+  const float* src2 = a.src[2];
+  // K loop, unrolled by two so that the two weight register sets alternate without copies
+  float4 wA[TAPS], wB[TAPS];
+  if (g_first < a.groups) {
+    DT_PREFETCH_PATCH(g_first);
+    DT_LOAD_WEIGHTS(wA, g_first);
+  }
+  for (int g = g_first; g < a.groups; g += 2 * g_step) {
+    DT_K_STEP(wA, wB, g);
+    if (g + g_step < a.groups) DT_K_STEP(wB, wA, g + g_step);
+  }
+#undef DT_K_STEP
+#undef DT_LOAD_WEIGHTS
+#undef DT_PREFETCH_PATCH
 
   const bool in_image = have_block && oy < a.h_out && ox < a.w_out;
   const size_t pix_off = (((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out;
