@@ -185,7 +185,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   // resident wave takes one contiguous span of floor/ceil(total / waves) units, i.e. one or two
   // partial tiles.  (With a fixed planes-per-task granularity the B=1 case left up to 25 % of the
   // waves one task short of the others.)
-  const long wid = (long)blockIdx.x * NWAVES + wave;
+  // XCD-aware order (blocks are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2): give
+  // every XCD one contiguous eighth of the span space, i.e. a band of image rows, so that the
+  // source-feature footprint of an XCD fits its L2 instead of every XCD streaming all 7 views.
+  const int nblk = gridDim.x;
+  const int lbid = (nblk % 8 == 0) ? (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const long wid = (long)lbid * NWAVES + wave;
   long u = wid * a.total_units / waves_total;
   const long u_end = (wid + 1) * a.total_units / waves_total;
   while (u < u_end) {
