@@ -128,14 +128,20 @@ __global__ __launch_bounds__(SPLIT == 8 ? 512 : 256) void conv_mfma_kernel(const
     _Pragma("unroll") for (int it = 0; it < NLOAD; ++it) {                                           \
       const int off = (sidx == 0) ? poff0[it] : ((sidx == 1) ? poff1[it] : poff2[it]);               \
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
-      if (off >= 0) v = *reinterpret_cast<const float4*>(sp + off);                                  \
+      if (!(DT_ABL & 2) && off >= 0) v = *reinterpret_cast<const float4*>(sp + off);                 \
       patch[it] = v;                                                                                 \
     }                                                                                                \
   } while (0)
+#ifndef DT_ABL
+#define DT_ABL 0
+#endif
 #define DT_LOAD_WEIGHTS(WREG, G)                                                                     \
   do {                                                                                               \
     const float4* wg = wbase + (size_t)(G) * (TAPS * 64);                                            \
-    _Pragma("unroll") for (int t = 0; t < TAPS; ++t) WREG[t] = wg[(size_t)t * 64];                   \
+    _Pragma("unroll") for (int t = 0; t < TAPS; ++t) {                                               \
+      if (DT_ABL & 1) WREG[t] = make_float4((float)(G), (float)t, 1.f, 2.f);                         \
+      else WREG[t] = wg[(size_t)t * 64];                                                             \
+    }                                                                                                \
   } while (0)
   // one K step: publish the prefetched patch, start the next group's loads, run this group's MFMAs
 #define DT_K_STEP(WCUR, WNXT, G)                                                                     \
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(SPLIT == 8 ? 512 : 256) void conv_mfma_kernel(const
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                           \
     _Pragma("unroll") for (int t = 0; t < TAPS; ++t) {                                               \
       const int ky = t / KS, kx = t - ky * KS;                                                       \
-      const float4 b4 =                                                                              \
+      const float4 b4 = (DT_ABL & 4) ? make_float4(acc[0], acc[1], 1.f, (float)t) :                  \
           *reinterpret_cast<const float4*>(tile + ((py * ST + ky) * IW + (px * ST + kx)) * 8 + half * 4); \
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WCUR[t].x, b4.x, acc, 0, 0, 0);                     \
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WCUR[t].y, b4.y, acc, 0, 0, 0);                     \
@@ -230,6 +236,209 @@ __global__ __launch_bounds__(SPLIT == 8 ? 512 : 256) void conv_mfma_kernel(const
         v[j] = sum;
       }
       if (in_image) finish(make_float4(v[0], v[1], v[2], v[3]), cb * 32 + wave * 8 + half * 4);
+    }
+  }
+}
+
+// ---- many-block layers: four pixel tiles per workgroup share the weight fragments through LDS -------
+// Ablation on the 240x320 128->64 layer (scripts/time_conv_layer.py, -DDT_ABL): of 139 us, 30 us were
+// stalls on the per-wave weight loads (every wave re-read all 147 KB of its channel block's weights
+// from L2) and 18 us on the patch loads.  Here the four waves of a workgroup own four pixel tiles of
+// the SAME 32-channel block; each wave fetches a quarter of the group's weight fragments one K step
+// ahead, publishes it to a double-buffered LDS slab, and all four read their A operands from there:
+// weight traffic per MFMA drops 4x, one workgroup barrier per K step (2304 MFMA cycles).
+template <int KS, int ST>
+__global__ __launch_bounds__(256) void conv_mfma_wshare_kernel(const ConvArgs a) {
+  constexpr int IH = (kPH - 1) * ST + KS, IW = (kPW - 1) * ST + KS;
+  constexpr int NPIX = IH * IW;
+  constexpr int NLOAD = (NPIX + 31) / 32;
+  constexpr int PAD = KS / 2;
+  constexpr int TAPS = KS * KS;
+  constexpr int WSHARE = (TAPS + 3) / 4;  // weight fragments fetched per wave and K step
+  __shared__ __attribute__((aligned(16))) float tiles[4 * NPIX * 8];
+  __shared__ __attribute__((aligned(16))) float wlds[2 * TAPS * 256];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, p = lane & 31;
+  const int py = p >> 3, px = p & 7;
+
+  const long px_tiles = (long)a.n * a.tiles_y * a.tiles_x;
+  const int cb = (int)(blockIdx.x % a.co_blocks);
+  long pt = (long)(blockIdx.x / a.co_blocks) * 4 + wave;
+  const bool have_tile = pt < px_tiles;
+  if (!have_tile) pt = px_tiles - 1;
+  const int tx = (int)(pt % a.tiles_x);
+  const int ty = (int)((pt / a.tiles_x) % a.tiles_y);
+  const int n = (int)(pt / ((long)a.tiles_x * a.tiles_y));
+
+  const int oy = ty * kPH + py, ox = tx * kPW + px;
+  const int iy0 = ty * kPH * ST - PAD, ix0 = tx * kPW * ST - PAD;
+  float* tile = tiles + wave * NPIX * 8;
+
+  int poff0[NLOAD], poff1[NLOAD], poff2[NLOAD];
+#pragma unroll
+  for (int it = 0; it < NLOAD; ++it) {
+    const int idx = (lane >> 1) + it * 32;
+    const int ly = idx / IW, lx = idx - ly * IW;
+    const int iy = iy0 + ly, ix = ix0 + lx;
+    const bool inside = idx < NPIX && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+    poff0[it] = pixel_offset(inside, n, iy, ix, a.h_in, a.w_in, a.up[0], a.c[0], lane);
+    poff1[it] = pixel_offset(inside && a.nsrc > 1, n, iy, ix, a.h_in, a.w_in, a.up[1], a.c[1], lane);
+    poff2[it] = pixel_offset(inside && a.nsrc > 2, n, iy, ix, a.h_in, a.w_in, a.up[2], a.c[2], lane);
+  }
+  const int ng0 = a.c[0] >> 3, ng1 = a.c[1] >> 3;
+  const float* src0 = a.src[0];
+  const float* src1 = a.src[1];
+  const float* src2 = a.src[2];
+  // packed weights: [cb][g][tap][half][32][4] -> fragment (g, t) is 64 consecutive float4, one per lane
+  const float4* wbase = reinterpret_cast<const float4*>(a.wp) + (size_t)cb * a.groups * TAPS * 64 + lane;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 patch[NLOAD];
+  float4 wq0 = make_float4(0.f, 0.f, 0.f, 0.f), wq1 = wq0, wq2 = wq0;  // named (an indexed array spills to scratch)
+
+#define DT_WS_PREFETCH(G)                                                                            \
+  do {                                                                                               \
+    const int g_ = (G);                                                                              \
+    const int sidx = (g_ < ng0) ? 0 : ((g_ < ng0 + ng1) ? 1 : 2);                                    \
+    const int gl = (sidx == 0) ? g_ : ((sidx == 1) ? g_ - ng0 : g_ - ng0 - ng1);                     \
+    const float* sp = ((sidx == 0) ? src0 : ((sidx == 1) ? src1 : src2)) + gl * 8;                   \
+    _Pragma("unroll") for (int it = 0; it < NLOAD; ++it) {                                           \
+      const int off = (sidx == 0) ? poff0[it] : ((sidx == 1) ? poff1[it] : poff2[it]);               \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+      if (off >= 0) v = *reinterpret_cast<const float4*>(sp + off);                                  \
+      patch[it] = v;                                                                                 \
+    }                                                                                                \
+    if (wave < TAPS) wq0 = wbase[((size_t)g_ * TAPS + wave) * 64];                                   \
+    if (WSHARE > 1 && wave + 4 < TAPS) wq1 = wbase[((size_t)g_ * TAPS + wave + 4) * 64];             \
+    if (WSHARE > 2 && wave + 8 < TAPS) wq2 = wbase[((size_t)g_ * TAPS + wave + 8) * 64];             \
+  } while (0)
+
+  DT_WS_PREFETCH(0);
+  for (int g = 0; g < a.groups; ++g) {
+    float* wbuf = wlds + (g & 1) * TAPS * 256;
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int idx = (lane >> 1) + it * 32;
+      if (idx < NPIX) *reinterpret_cast<float4*>(tile + idx * 8 + (lane & 1) * 4) = patch[it];
+    }
+    if (wave < TAPS) *reinterpret_cast<float4*>(wbuf + wave * 256 + lane * 4) = wq0;
+    if (WSHARE > 1 && wave + 4 < TAPS) *reinterpret_cast<float4*>(wbuf + (wave + 4) * 256 + lane * 4) = wq1;
+    if (WSHARE > 2 && wave + 8 < TAPS) *reinterpret_cast<float4*>(wbuf + (wave + 8) * 256 + lane * 4) = wq2;
+    if (g + 1 < a.groups) DT_WS_PREFETCH(g + 1);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int ky = t / KS, kx = t - ky * KS;
+      const float4 a4 = *reinterpret_cast<const float4*>(wbuf + t * 256 + lane * 4);
+      const float4 b4 = *reinterpret_cast<const float4*>(tile + ((py * ST + ky) * IW + (px * ST + kx)) * 8 + half * 4);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+  }
+#undef DT_WS_PREFETCH
+
+  if (have_tile && oy < a.h_out && ox < a.w_out) {
+    const size_t pix_off = (((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = cb * 32 + q * 8 + half * 4;
+      const size_t off = pix_off + co;
+      float4 o = make_float4(acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+      if (a.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+        o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+      }
+      if (a.res) {
+        const float4 rv = *reinterpret_cast<const float4*>(a.res + off);
+        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+      }
+      o.x = apply_act(o.x, a.act); o.y = apply_act(o.y, a.act); o.z = apply_act(o.z, a.act); o.w = apply_act(o.w, a.act);
+      *reinterpret_cast<float4*>(a.out + off) = o;
+    }
+  }
+}
+
+// ---- 1x1 convolution: no LDS, operands straight from global memory, 8 K-groups in flight -----------
+// A 1x1 conv is a plain GEMM over the flattened pixel index: the lane that owns pixel p / k-half h
+// loads its own B fragment (4 consecutive channels) directly, so nothing is staged and eight
+// 8-channel groups (16 dwordx4 loads per lane) are issued before their 32 MFMAs -- with one tap per
+// group there is no other way to cover the load latency.  One wave = one 32-channel x 32-pixel block.
+__global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, p = lane & 31;
+  const long npix = (long)a.n * a.h_out * a.w_out;
+  const long pix_blocks = (npix + 31) / 32;
+  long bid = (long)blockIdx.x * 4 + wave;
+  const bool have_block = bid < pix_blocks * a.co_blocks;
+  if (!have_block) bid = pix_blocks * a.co_blocks - 1;
+  const int cb = (int)(bid % a.co_blocks);
+  const long pb = bid / a.co_blocks;
+  const long pix = pb * 32 + p;
+  const bool live = have_block && pix < npix;
+  const long pc = pix < npix ? pix : npix - 1;
+  const int ox = (int)(pc % a.w_out);
+  const int oy = (int)((pc / a.w_out) % a.h_out);
+  const int n = (int)(pc / ((long)a.w_out * a.h_out));
+  // element offset of this lane's pixel (+ its 4-channel half) in each source
+  const int off0 = pixel_offset(true, n, oy, ox, a.h_in, a.w_in, a.up[0], a.c[0], half);
+  const int off1 = pixel_offset(a.nsrc > 1, n, oy, ox, a.h_in, a.w_in, a.up[1], a.c[1], half);
+  const int off2 = pixel_offset(a.nsrc > 2, n, oy, ox, a.h_in, a.w_in, a.up[2], a.c[2], half);
+  const int ng0 = a.c[0] >> 3, ng1 = a.c[1] >> 3;
+  const float* src0 = a.src[0];
+  const float* src1 = a.src[1];
+  const float* src2 = a.src[2];
+  const float4* wbase = reinterpret_cast<const float4*>(a.wp) + ((size_t)cb * a.groups * 2 + half) * 32 + p;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int U = 8;
+  for (int g0 = 0; g0 < a.groups; g0 += U) {
+    float4 bq[U], aq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int g = min(g0 + u, a.groups - 1);
+      const int sidx = (g < ng0) ? 0 : ((g < ng0 + ng1) ? 1 : 2);
+      const int gl = (sidx == 0) ? g : ((sidx == 1) ? g - ng0 : g - ng0 - ng1);
+      const float* sp = ((sidx == 0) ? src0 : ((sidx == 1) ? src1 : src2)) + gl * 8;
+      const int off = (sidx == 0) ? off0 : ((sidx == 1) ? off1 : off2);
+      bq[u] = *reinterpret_cast<const float4*>(sp + off);
+      aq[u] = wbase[(size_t)g * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (g0 + u < a.groups) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u].x, bq[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u].y, bq[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u].z, bq[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u].w, bq[u].w, acc, 0, 0, 0);
+      }
+    }
+  }
+  if (live) {
+    const size_t pix_off = (size_t)pix * a.c_out;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = cb * 32 + q * 8 + half * 4;
+      const size_t off = pix_off + co;
+      float4 o = make_float4(acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+      if (a.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+        o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+      }
+      if (a.res) {
+        const float4 rv = *reinterpret_cast<const float4*>(a.res + off);
+        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+      }
+      o.x = apply_act(o.x, a.act); o.y = apply_act(o.y, a.act); o.z = apply_act(o.z, a.act); o.w = apply_act(o.w, a.act);
+      *reinterpret_cast<float4*>(a.out + off) = o;
     }
   }
 }
@@ -425,12 +634,13 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
   // otherwise split K over 4 or 8 waves so that small layers still occupy the chip.
   const long k_steps = (long)a.groups * d->ksize * d->ksize;  // groups x taps per block
   int split = 4;
-  if (blocks >= 4096 || k_steps <= 16) split = 1;
+  if (blocks >= 4096 || k_steps <= 16) split = 1;  // (at 1200 blocks the 4-way K split measured faster)
   else if (blocks * 4 < 2048 && a.groups >= 16) split = 8;
 #define DT_LAUNCH_CONV(KS_, ST_)                                                                                   \
   do {                                                                                                             \
     if (split == 1)                                                                                                \
-      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 1>), dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, a); \
+      hipLaunchKernelGGL((conv_mfma_wshare_kernel<KS_, ST_>),                                                      \
+                         dim3((unsigned)((((long)a.n * a.tiles_y * a.tiles_x + 3) / 4) * a.co_blocks)), dim3(256), 0, st, a); \
     else if (split == 4)                                                                                           \
       hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a);             \
     else                                                                                                           \
@@ -440,8 +650,11 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
     DT_LAUNCH_CONV(3, 1);
   else if (d->ksize == 3 && d->stride == 2)
     DT_LAUNCH_CONV(3, 2);
-  else
-    DT_LAUNCH_CONV(1, 1);
+  else {
+    const long pix_blocks = ((long)a.n * a.h_out * a.w_out + 31) / 32;
+    const long waves = pix_blocks * a.co_blocks;
+    hipLaunchKernelGGL(conv1x1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+  }
 #undef DT_LAUNCH_CONV
   return check_launch("dt_conv2d_f32");
 }

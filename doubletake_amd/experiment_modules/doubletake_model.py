@@ -57,8 +57,12 @@ class DepthModelCVHint(nn.Module):
         """cur_feats: list of 5 image-prior maps (strides 2..32); matching feats at stride 4.
         Returns the reference's output dict (doubletake_model.py:410-423)."""
         dev = matching_cur_feats.device
-        min_depth = torch.tensor(self.min_matching_depth, device=dev, dtype=torch.float32).view(1, 1, 1, 1)
-        max_depth = torch.tensor(self.max_matching_depth, device=dev, dtype=torch.float32).view(1, 1, 1, 1)
+        key = (str(dev), self.min_matching_depth, self.max_matching_depth)
+        if getattr(self, "_depth_range_key", None) != key:  # device-resident constants, built once
+            self._min_depth = torch.tensor(self.min_matching_depth, device=dev, dtype=torch.float32).view(1, 1, 1, 1)
+            self._max_depth = torch.tensor(self.max_matching_depth, device=dev, dtype=torch.float32).view(1, 1, 1, 1)
+            self._depth_range_key = key
+        min_depth, max_depth = self._min_depth, self._max_depth
         cost_volume, lowest_cost, _, overall_mask = self.cost_volume(
             cur_feats=matching_cur_feats, src_feats=matching_src_feats, src_extrinsics=src_cam_T_cur_cam,
             src_poses=cur_cam_T_src_cam, src_Ks=src_K, cur_invK=cur_invK, min_depth=min_depth, max_depth=max_depth,

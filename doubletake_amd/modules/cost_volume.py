@@ -120,8 +120,12 @@ class CostVolumeManager(nn.Module):
         ext = _f32c(src_extrinsics).view(b, k, 4, 4)
         poses = _f32c(src_poses).view(b, k, 4, 4)
         invK = _f32c(cur_invK).view(b, 4, 4)
-        mn = _f32c(min_depth.to(dev)).reshape(-1).expand(b).contiguous() if min_depth.numel() != b else _f32c(min_depth.to(dev)).reshape(b)
-        mx = _f32c(max_depth.to(dev)).reshape(-1).expand(b).contiguous() if max_depth.numel() != b else _f32c(max_depth.to(dev)).reshape(b)
+        mn = _f32c(min_depth.to(dev)).reshape(-1)
+        mx = _f32c(max_depth.to(dev)).reshape(-1)
+        if mn.numel() != b:  # the reference passes [1,1,1,1] tensors for any batch size
+            mn = mn.expand(b).contiguous()
+        if mx.numel() != b:
+            mx = mx.expand(b).contiguous()
         pf = L.dt_cv_params_floats(D, k)
         params = torch.empty(b, pf, device=dev, dtype=torch.float32)
         _abi.check(L.dt_cv_setup_f32(_abi.ptr(Ks), _abi.ptr(ext), _abi.ptr(poses), _abi.ptr(invK), _abi.ptr(mn),

@@ -72,11 +72,18 @@ class KeyframeShardFuser:
         _, K, T = syn.tsdf_frames(pool, self.h, self.w, seed=5, bounds=self.BOUNDS)
         self.K_pool = torch.from_numpy(K).to(device)
         self.T_pool = torch.from_numpy(T).to(device)
+        self.K_pool16 = self.K_pool.half()
+        self.T_pool16 = self.T_pool.half()
         self.pool = pool
 
     def exchange_and_fuse(self, depth_b1hw: torch.Tensor, frame_idx: int):
         b = depth_b1hw.shape[0]
         gidx = [(frame_idx * self.world + self.rank) * b + i for i in range(b)]
+        if self.world == 1 and b == 1:
+            # single GPU: nothing to exchange -- integrate the own frame directly (no packing kernels)
+            j = gidx[0] % self.pool
+            self.fuse_fn(depth_b1hw, self.K_pool16[j:j + 1], self.T_pool16[j:j + 1])
+            return 1
         sel = torch.tensor([g % self.pool for g in gidx], device=self.device)
         local = pack_update(depth_b1hw, self.K_pool[sel], self.T_pool[sel])
         allbuf = exchange_updates(local, self.world)
