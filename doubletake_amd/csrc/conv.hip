@@ -38,7 +38,7 @@ struct ConvArgs {
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == DT_ACT_LRELU02) return v >= 0.f ? v : 0.2f * v;
-  if (act == DT_ACT_ELU) return v > 0.f ? v : expm1f(v);
+  if (act == DT_ACT_ELU) return v > 0.f ? v : __expf(v) - 1.0f;  // ATen's elu: exp(x) - 1
   return v;
 }
 

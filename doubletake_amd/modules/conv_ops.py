@@ -150,6 +150,38 @@ def conv1x1_head(x, conv: nn.Conv2d):
     return out
 
 
+def head_mlp(x, head: nn.Sequential):
+    """Fused 1x1 -> ELU -> 1x1 -> ELU -> 1x1 regression head (modules/networks_fast.py:102-132).
+    x NHWC [n,c,h,w] (c = 64 or 128) -> [n,1,h,w]."""
+    from . import mlp_pack
+
+    L = _abi.lib()
+    ca, cb_, cc = head[0], head[2], head[4]
+    n, c, h, w = x.shape
+    dev = x.device
+    params = [ca.weight, ca.bias, cb_.weight, cb_.bias, cc.weight, cc.bias]
+    key = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+    hit = head.__dict__.get("_dt_head_pack")
+    if hit is None or hit[0] != key:
+        arrs = [p.detach().float().cpu().numpy() for p in params]
+        pk = mlp_pack.pack_head_mlp(*arrs)
+        hit = (key, {k: torch.from_numpy(v).to(dev) for k, v in pk.items()})
+        head.__dict__["_dt_head_pack"] = hit
+    pk = hit[1]
+    out = torch.empty((n, 1, h, w), device=dev, dtype=torch.float32)
+    _abi.check(L.dt_head_mlp_f32(_abi.ptr(x), _abi.ptr(pk["wa"]), _abi.ptr(pk["wb"]), _abi.ptr(pk["tail"]), _abi.ptr(out),
+                                 n * h * w, c, _abi.current_stream(dev)), "dt_head_mlp_f32")
+    return out
+
+
+def head_mlp_supported(x, head) -> bool:
+    try:
+        return (x.shape[1] in (64, 128) and len(head) == 5 and head[0].out_channels == 128 and head[2].out_channels == 128
+                and head[4].out_channels == 1 and all(head[i].kernel_size == (1, 1) for i in (0, 2, 4)))
+    except Exception:
+        return False
+
+
 def upsample2x_bilinear(x):
     """utils/generic_utils.py:95-104 on an NHWC tensor."""
     L = _abi.lib()

@@ -172,3 +172,40 @@ def emulate_packed_mlp(packed, x_cols, K):
             for r in range(16):
                 s += tail[128 + h * 64 + blk * 16 + r] * h2[:, acc_feature(blk, r, h)]
     return s + tail[256]
+
+
+HEAD_TAIL_FLOATS = 388
+
+
+def pack_head_mlp(Wa, ba, Wb, bb, Wc, bc):
+    """Regression head Cin -> 128 -> 128 -> 1 (1x1 convs of SkipDecoderRegression.out*) for
+    csrc/head_mlp.hip.  Layer A step 4g+j feeds input channels (8g+j | 8g+4+j) from the two lane
+    halves (the halves of the float4 each lane loads); layer B uses the accumulator order."""
+    Wa = np.asarray(Wa, np.float32).reshape(HID, -1)
+    cin = Wa.shape[1]
+    if cin not in (64, 128):
+        raise ValueError("fused head supports 64 or 128 input channels")
+    Wb = np.asarray(Wb, np.float32).reshape(HID, HID)
+    tabA = np.zeros((cin // 2, 2), dtype=np.int64)
+    for g in range(cin // 8):
+        for j in range(4):
+            tabA[4 * g + j] = (8 * g + j, 8 * g + 4 + j)
+    wa = _pack_steps(np.concatenate([Wa, np.zeros((HID, 2), np.float32)], 1), tabA)
+    tabB = np.zeros((W2_STEPS, 2), dtype=np.int64)
+    for t in range(W2_STEPS):
+        for h in range(2):
+            tabB[t, h] = acc_feature(t >> 4, t & 15, h)
+    wb = _pack_steps(np.concatenate([Wb, np.zeros((HID, 2), np.float32)], 1), tabB)
+    tail = np.zeros(HEAD_TAIL_FLOATS, dtype=np.float32)
+    ba = np.asarray(ba, np.float32).reshape(-1)
+    bb = np.asarray(bb, np.float32).reshape(-1)
+    wc = np.asarray(Wc, np.float32).reshape(-1)
+    for h in range(2):
+        for blk in range(4):
+            for r in range(16):
+                f = acc_feature(blk, r, h)
+                tail[h * 64 + blk * 16 + r] = ba[f]
+                tail[128 + h * 64 + blk * 16 + r] = bb[f]
+                tail[256 + h * 64 + blk * 16 + r] = wc[f]
+    tail[384] = np.asarray(bc, np.float32).reshape(-1)[0]
+    return dict(wa=wa.reshape(-1), wb=wb.reshape(-1), tail=tail)

@@ -83,7 +83,12 @@ class SkipDecoderRegression(SkipDecoder):
         out = self._features(features, impl=_impl)
         for oi, scale in ((1, 3), (2, 2), (3, 1), (4, 0)):
             head = getattr(self, f"out{oi}")
-            y = ops.conv2d([(out[f"feature_s{scale}_b1hw"], False)], head[0], act=ops.ACT_ELU, impl=_impl)
+            feat = out[f"feature_s{scale}_b1hw"]
+            if _impl == "mfma" and ops.head_mlp_supported(feat, head):
+                # 64- and 128-channel heads (scales 0-2, 99 % of the pixels): one fused kernel
+                out[f"log_depth_pred_s{scale}_b1hw"] = ops.head_mlp(feat, head)
+                continue
+            y = ops.conv2d([(feat, False)], head[0], act=ops.ACT_ELU, impl=_impl)
             y = ops.conv2d([(y, False)], head[2], act=ops.ACT_ELU, impl=_impl)
             out[f"log_depth_pred_s{scale}_b1hw"] = ops.conv1x1_head(y, head[4])
         return out

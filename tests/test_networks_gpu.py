@@ -183,3 +183,47 @@ def test_small_model_graph_full_size_mfma_vs_simple():
         err = (a[k] - b[k]).abs().max().item()
         assert err < 2e-4, f"{k}: {err}"
     assert tuple(a["log_depth_pred_s0_b1hw"].shape) == (1, 1, 2 * h, 2 * w)
+
+
+def test_full_model_graph_full_size_mfma_vs_simple():
+    """DoubleTake full model decoder (DepthDecoderPP, EfficientNetV2-S widths) at 120x160 / D=64."""
+    import gpu_util as gu
+    from doubletake_amd.modules.networks import CVEncoder, DepthDecoderPP
+
+    enc = [24, 48, 64, 160, 256]
+    h, w, Dp = 120, 160, 64
+    cve = CVEncoder(Dp, enc[1:], [64, 128, 256, 384]).to(gu.dev())
+    gu.set_formula_weights(cve, 21)
+    dec = DepthDecoderPP([enc[0], 64, 128, 256, 384]).to(gu.dev())
+    gu.set_formula_weights(dec, 22, scale_mult=0.7)
+    vol = _t(syn.hash_normalish((1, Dp, h, w), 3))
+    feats = [_t(f) for f in syn.prior_pyramid(1, enc, 2 * h, 2 * w, 4)]
+    a = dec([feats[0]] + cve(vol, feats[1:]))
+    b = dec([feats[0]] + cve(vol, feats[1:], _impl="simple"), _impl="simple")
+    torch.cuda.synchronize()
+    for k in a:
+        err = (a[k] - b[k]).abs().max().item()
+        assert err < 5e-4, f"{k}: {err}"
+    assert tuple(a["log_depth_pred_s0_b1hw"].shape) == (1, 1, 2 * h, 2 * w)
+
+
+def test_batched_conv_graph_equals_per_sample():
+    """Batch 3 through the small-model graph equals three batch-1 runs (n is just another tile index);
+    not bit-equal because the K-split policy -- hence the fp32 summation order -- depends on the block count."""
+    import gpu_util as gu
+    from doubletake_amd.modules.networks import CVEncoder
+    from doubletake_amd.modules.networks_fast import SkipDecoderRegression
+
+    enc = [64, 64, 128, 256, 512]
+    h, w, Dp = 24, 40, 16
+    cve = CVEncoder(Dp, enc[1:], [64, 128, 256, 384]).to(gu.dev())
+    gu.set_formula_weights(cve, 5)
+    dec = SkipDecoderRegression([enc[0], 64, 128, 256, 384]).to(gu.dev())
+    gu.set_formula_weights(dec, 6)
+    vol = _t(syn.hash_normalish((3, Dp, h, w), 8))
+    feats = [_t(f) for f in syn.prior_pyramid(3, enc, 2 * h, 2 * w, 9)]
+    full = dec([feats[0]] + cve(vol, feats[1:]))
+    for i in range(3):
+        one = dec([feats[0][i:i + 1]] + cve(vol[i:i + 1], [f[i:i + 1] for f in feats[1:]]))
+        for k in full:
+            assert (full[k][i:i + 1] - one[k]).abs().max().item() < 2e-5, k

@@ -153,3 +153,47 @@ def test_linearity_in_last_layer_at_full_size():
     torch.cuda.synchronize()
     assert torch.isfinite(v1).all()
     assert (v2 - 2.0 * v1).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("name,b,k,h,w,D", [
+    ("cfg3_batch8", 8, 7, 96, 128, 64),          # BASELINE configs[2]: ScanNet default 512x384, batch 8
+    ("cfg5_portrait_D96", 2, 7, 128, 96, 96),    # BASELINE configs[4]: 3RScan rotated (portrait), 96 planes
+])
+def test_other_baseline_configs_mfma_vs_simple_and_oracle_probes(name, b, k, h, w, D):
+    """Larger BASELINE shapes: the fused MFMA kernel against the independent one-thread-per-pair GPU
+    kernel on the whole tensor, and against the numpy oracle on one batch element / 6 planes."""
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import FeatureMeshHintVolumeManager
+    from oracle import cost_volume_ref as ref
+
+    inp = syn.volume_inputs(b, k, h, w, 16, 21)
+    t = gu.to_dev(inp)
+    m = FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    mw = gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 31)
+    hw_ = gu.load_formula_mlp(m.hint_mlp, [3, 12, 12, 1], 32)
+    args = dict(**gu.volume_call_args(t), cv_depth_hint_dict=gu.hint_dict(t), depth_planes_bdhw=None, return_mask=True)
+    va, la, pa, ma = m._forward_impl(**args, _impl="mfma")
+    vb, lb, pb, mb = m._forward_impl(**args, _impl="simple")
+    torch.cuda.synchronize()
+    assert tuple(va.shape) == (b, D, h, w)
+    assert (va - vb).abs().max().item() < 5e-5
+    assert torch.equal(ma, mb) and tuple(ma.shape) == (b, k, h, w)
+    # oracle on the last batch element, a few planes (full oracle run at this size takes minutes)
+    planes = ref.generate_depth_planes(inp["min_depth"], inp["max_depth"], D)
+    np.testing.assert_allclose(pa[:, :, 0, 0].cpu().numpy(), planes, rtol=3e-6)
+    bi = b - 1
+    sel = lambda a: a[bi:bi + 1]
+    hd = nearest = None
+    for d in (0, 1, D // 2, D - 2, D - 1):
+        feats, z, mask, pix = ref.mlp_input_features(sel(inp["cur_feats"]), sel(inp["src_feats"]), sel(inp["src_extrinsics"]),
+                                                     sel(inp["src_poses"]), sel(inp["src_Ks"]), sel(inp["cur_invK"]), planes[bi:bi + 1, d])
+        s = ref.mlp_forward(feats.reshape(h * w, -1), mw).reshape(h * w)
+        hdm = ref.nearest_resize(sel(inp["depth_hint_b1hw"]), h, w).reshape(-1)
+        hwm = ref.nearest_resize(sel(inp["sampled_weights_b1hw"]), h, w).reshape(-1).copy()
+        hmm = ref.nearest_resize(sel(inp["depth_hint_mask_b1hw"]), h, w).reshape(-1) != 0
+        hwm[~hmm] = 0
+        with np.errstate(invalid="ignore"):
+            hmap = np.where(hmm, np.abs(hdm - planes[bi, d]), np.float32(-1)).astype(np.float32)
+        want = ref.mlp_forward(np.stack([s, hmap, hwm], -1), hw_).reshape(h, w)
+        got = va[bi, d].cpu().numpy()
+        assert np.abs(got - want).max() < 5e-5, (name, d)
