@@ -1,0 +1,96 @@
+// Depth rasteriser for the hint mesh, gfx950.
+//
+// Replaces the PyTorch3D MeshRasterizer call of the reference's hint renderer
+// (utils/rendering_utils.py:9-53: image_size=(h,w), blur_radius=0, faces_per_pixel=1, perspective
+// cameras built by cameras_from_opencv_projection; only fragments.zbuf is used, background -1).
+// Semantics restated: a pixel is covered by a triangle when its centre (x+0.5, y+0.5) lies inside
+// the projected triangle (no back-face culling); zbuf is the perspective-correct depth
+// 1 / sum(b_i / z_i) of the nearest such triangle.  Faces with a vertex closer than z = 1e-2 are
+// dropped (PyTorch3D clips them at that plane; they are centimetre-sized triangles at the camera).
+// PyTorch3D 0.7.4 is not installed here, so parity with it is UNPINNED; the oracle is an independent
+// numpy restatement of the semantics above (oracle/raster_ref.py).
+//
+// One thread per triangle, depth test with atomicMin on the IEEE bits (z > 0 => order preserving).
+// Hint meshes are 0.04 m marching-cubes triangles seen from 0.5-3 m: a few pixels each, so the
+// per-thread bounding-box loop is short and the kernel is bound by the vertex gather.
+#include "common.hpp"
+
+namespace dt {
+
+__global__ void raster_init_kernel(uint32_t* __restrict__ zb, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) zb[i] = 0xFFFFFFFFu;
+}
+
+__global__ void raster_faces_kernel(const float* __restrict__ verts, const int64_t* __restrict__ faces, int64_t num_faces,
+                                    const float* __restrict__ cam_T_world, const float* __restrict__ K, int h, int w,
+                                    uint32_t* __restrict__ zb) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= num_faces) return;
+  const float fx = K[0], cx = K[2], fy = K[5], cy = K[6];
+  float sx[3], sy[3], sz[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int64_t vi = faces[f * 3 + i];
+    const float X = verts[vi * 3 + 0], Y = verts[vi * 3 + 1], Z = verts[vi * 3 + 2];
+    const float xc = cam_T_world[0] * X + cam_T_world[1] * Y + cam_T_world[2] * Z + cam_T_world[3];
+    const float yc = cam_T_world[4] * X + cam_T_world[5] * Y + cam_T_world[6] * Z + cam_T_world[7];
+    const float zc = cam_T_world[8] * X + cam_T_world[9] * Y + cam_T_world[10] * Z + cam_T_world[11];
+    if (!(zc > 1e-2f)) return;
+    sx[i] = fx * xc / zc + cx;
+    sy[i] = fy * yc / zc + cy;
+    sz[i] = zc;
+  }
+  const float area = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sx[2] - sx[0]) * (sy[1] - sy[0]);
+  if (fabsf(area) < 1e-12f) return;
+  const float inv_area = 1.0f / area;
+  const float minx = fminf(sx[0], fminf(sx[1], sx[2])), maxx = fmaxf(sx[0], fmaxf(sx[1], sx[2]));
+  const float miny = fminf(sy[0], fminf(sy[1], sy[2])), maxy = fmaxf(sy[0], fmaxf(sy[1], sy[2]));
+  const int x0 = max(0, (int)ceilf(minx - 0.5f)), x1 = min(w - 1, (int)floorf(maxx - 0.5f));
+  const int y0 = max(0, (int)ceilf(miny - 0.5f)), y1 = min(h - 1, (int)floorf(maxy - 0.5f));
+  const float iz0 = 1.0f / sz[0], iz1 = 1.0f / sz[1], iz2 = 1.0f / sz[2];
+  for (int y = y0; y <= y1; ++y) {
+    const float py = (float)y + 0.5f;
+    for (int x = x0; x <= x1; ++x) {
+      const float px = (float)x + 0.5f;
+      // barycentrics from edge functions, normalised by the signed area (either winding)
+      const float b0 = ((sx[1] - px) * (sy[2] - py) - (sx[2] - px) * (sy[1] - py)) * inv_area;
+      const float b1 = ((sx[2] - px) * (sy[0] - py) - (sx[0] - px) * (sy[2] - py)) * inv_area;
+      const float b2 = 1.0f - b0 - b1;
+      if (b0 < 0.f || b1 < 0.f || b2 < 0.f) continue;
+      const float z = 1.0f / (b0 * iz0 + b1 * iz1 + b2 * iz2);
+      if (z > 0.f) atomicMin(zb + (size_t)y * w + x, __float_as_uint(z));
+    }
+  }
+}
+
+__global__ void raster_resolve_kernel(const uint32_t* __restrict__ zb, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t b = zb[i];
+    out[i] = (b == 0xFFFFFFFFu) ? -1.0f : __uint_as_float(b);
+  }
+}
+
+}  // namespace dt
+
+using namespace dt;
+
+extern "C" {
+
+int dt_raster_depth_f32(const float* verts_v3, const int64_t* faces_f3, int64_t num_faces, const float* cam_T_world_44,
+                        const float* K_44, int h, int w, uint32_t* workspace_hw, float* depth_hw, dt_stream_t s) {
+  DT_REQUIRE(cam_T_world_44 && K_44 && workspace_hw && depth_hw, "dt_raster_depth_f32: null pointer");
+  DT_REQUIRE(h > 0 && w > 0 && num_faces >= 0, "dt_raster_depth_f32: bad extents");
+  DT_REQUIRE(num_faces == 0 || (verts_v3 && faces_f3), "dt_raster_depth_f32: null mesh");
+  const int64_t n = (int64_t)h * w;
+  hipStream_t st = to_stream(s);
+  hipLaunchKernelGGL(raster_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, n);
+  if (num_faces > 0)
+    hipLaunchKernelGGL(raster_faces_kernel, dim3((unsigned)((num_faces + 127) / 128)), dim3(128), 0, st, verts_v3, faces_f3,
+                       num_faces, cam_T_world_44, K_44, h, w, workspace_hw);
+  hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, depth_hw, n);
+  return check_launch("dt_raster_depth_f32");
+}
+
+}  // extern "C"

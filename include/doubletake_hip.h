@@ -215,6 +215,15 @@ int dt_mc_generate(const uint16_t* values_f16, const uint32_t* active, int X, in
                    const void* workspace, float* verts_v3, int64_t* faces_f3, int64_t* ids_v,
                    int num_verts, dt_stream_t s);
 
+/* ---- hint-mesh depth render --------------------------------------------
+ * replaces: PyTorch3DMeshDepthRenderer.render (utils/rendering_utils.py:22-53) = PyTorch3D
+ * MeshRasterizer(image_size=(h,w), blur_radius=0, faces_per_pixel=1).zbuf, background -1.
+ * verts in world coordinates, faces int64 [F,3]; cam_T_world_44 / K_44 (PIXEL-unit intrinsics):
+ * device, 16 floats row-major; workspace_hw: h*w uint32.  Parity with PyTorch3D is unpinned. */
+int dt_raster_depth_f32(const float* verts_v3, const int64_t* faces_f3, int64_t num_faces,
+                        const float* cam_T_world_44, const float* K_44, int h, int w,
+                        uint32_t* workspace_hw, float* depth_hw, dt_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif
