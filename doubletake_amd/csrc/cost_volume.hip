@@ -221,15 +221,60 @@ __global__ __launch_bounds__(128) void cv_mlp_simple_kernel(
 __global__ void cv_lowest_cost_kernel(const float* __restrict__ vol, const float* __restrict__ params,
                                       float* __restrict__ out, int nhwc, int K, size_t hw, int D) {
   const int b = blockIdx.y;
+  const float* p = params + (size_t)b * cv_params_floats(D, K);
+  if (nhwc) {
+    // [pixel][D] layout: 16 lanes share one pixel (coalesced float4 reads of its D contiguous costs),
+    // then a 16-lane butterfly picks the maximum, lowest plane index winning ties (= first maximum)
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t pix = t >> 4;
+    const int sub = (int)(t & 15);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    bool nan_seen = false;
+    if (pix < hw) {
+      const float* row = vol + ((size_t)b * hw + pix) * D;
+      for (int d = sub * 4; d < D; d += 64) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (d + j >= D) break;
+          const float v = row[d + j];
+          if (v != v) {  // torch.argmax treats NaN as the maximum (first NaN wins)
+            if (!nan_seen) {
+              nan_seen = true;
+              bi = d + j;
+            }
+          } else if (!nan_seen && (bi == 0x7fffffff || v > best)) {
+            best = v;
+            bi = d + j;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+      const float ob = __shfl_xor(best, m, 64);
+      const int oi = __shfl_xor(bi, m, 64);
+      const int on = __shfl_xor((int)nan_seen, m, 64);
+      bool take;
+      if (on != (int)nan_seen) take = on != 0;          // a NaN beats any number
+      else if (nan_seen) take = oi < bi;                 // both NaN: first index
+      else take = (ob > best) || (ob == best && oi < bi);
+      if (take) {
+        best = ob;
+        bi = oi;
+        nan_seen = on != 0;
+      }
+    }
+    if (pix < hw && sub == 0) out[(size_t)b * hw + pix] = p[kCvPlanes + (bi == 0x7fffffff ? 0 : bi)];
+    return;
+  }
   const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= hw) return;
-  const float* p = params + (size_t)b * cv_params_floats(D, K);
   float best = -INFINITY;
   int bi = 0;
   bool seen_nan = false;
   for (int d = 0; d < D; ++d) {
-    const float v = nhwc ? vol[((size_t)b * hw + pix) * D + d] : vol[((size_t)b * D + d) * hw + pix];
-    // torch.argmax treats NaN as the maximum (first NaN wins)
+    const float v = vol[((size_t)b * D + d) * hw + pix];
     if (!seen_nan && (v != v)) {
       seen_nan = true;
       bi = d;
@@ -327,7 +372,8 @@ int dt_cv_lowest_cost_f32(const float* volume, const float* params, float* lowes
   DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0 && num_src > 0, "dt_cv_lowest_cost_f32: bad extents");
   DT_REQUIRE(volume && params && lowest, "dt_cv_lowest_cost_f32: null pointer");
   const size_t hw = (size_t)h * w;
-  dim3 grid((unsigned)((hw + 255) / 256), batch);
+  const size_t threads = nhwc ? hw * 16 : hw;
+  dim3 grid((unsigned)((threads + 255) / 256), batch);
   hipLaunchKernelGGL(cv_lowest_cost_kernel, grid, dim3(256), 0, to_stream(s), volume, params, lowest, nhwc, num_src, hw,
                      num_planes);
   return check_launch("dt_cv_lowest_cost_f32");
