@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse", action="store_true", help="skip the TSDF integration of the gathered frames")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the model part of the step from 3 hipGraphs (cut around the dominant kernel) instead of "
+                         "launching eagerly; measured no faster -- the eager step is already GPU-bound (DESIGN.md 4.3)")
     args = ap.parse_args()
 
     import torch
@@ -132,9 +135,56 @@ def main():
         ev.record(torch.cuda.current_stream(device))
         events.append((tag, ev))
 
-    def step(frame_idx):
-        out = model.forward_from_features(pyr_t, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"],
-                                          t["src_Ks"], t["cur_invK"], hint, return_mask=True)
+    def model_step():
+        return model.forward_from_features(pyr_t, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"],
+                                           t["src_Ks"], t["cur_invK"], hint, return_mask=True)
+
+    # ---- hipGraph capture of the model part of a step, cut into three graphs at the dominant kernel so
+    # that HIP events recorded between the replays bracket exactly cv_mlp_mfma_kernel -------------------
+    graphs = None
+    if args.graph:
+        try:
+            for _ in range(3):  # allocator / weight-pack warm-up outside capture
+                model_step()
+            torch.cuda.synchronize(device)
+            pool = torch.cuda.graph_pool_handle()
+            gs = [torch.cuda.CUDAGraph() for _ in range(3)]
+            cap_stream = torch.cuda.Stream(device)
+            state = {"i": 0}
+
+            def cut(tag):
+                gs[state["i"]].capture_end()
+                state["i"] += 1
+                gs[state["i"]].capture_begin(pool=pool)
+
+            cvmod.FeatureVolumeManager._event_hook = staticmethod(cut)
+            cap_stream.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(cap_stream):
+                gs[0].capture_begin(pool=pool)
+                static_out = model_step()
+                gs[state["i"]].capture_end()
+            torch.cuda.current_stream(device).wait_stream(cap_stream)
+            cvmod.FeatureVolumeManager._event_hook = None
+            assert state["i"] == 2
+            graphs = (gs, static_out)
+        except Exception as e:  # capture unsupported: run eagerly and say so
+            cvmod.FeatureVolumeManager._event_hook = None
+            graphs = None
+            print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
+            torch.cuda.synchronize(device)
+
+    def step(frame_idx, timed=False):
+        if graphs is not None:
+            gs, out = graphs
+            gs[0].replay()
+            if timed:
+                hook("mlp_begin")
+            gs[1].replay()
+            if timed:
+                hook("mlp_end")
+            gs[2].replay()
+        else:
+            out = model_step()
         if fuser is not None:
             fuser.exchange_and_fuse(out["depth_pred_s0_b1hw"], frame_idx)
         return out
@@ -145,10 +195,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
-    cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
+    if graphs is None:
+        cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(args.warmup + i, timed=True)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -196,6 +247,7 @@ def main():
                             "640x480, 7 source views, 64 planes, batch=1 per GPU (BASELINE.json configs[1])",
                 "matching_resolution": [h, w],
                 "frames_per_step_per_gpu": CFG["batch"],
+                "launch": "3 hipGraphs per step (cut around the dominant kernel) + eager TSDF exchange/integrate" if graphs is not None else "eager",
                 "parallelism": f"keyframe-shard x{world}" + ("" if args.no_fuse else " + all_gather(depth,K,pose) + replica TSDF integrate"),
             },
             "roofline": {

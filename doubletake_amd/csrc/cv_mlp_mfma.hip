@@ -39,6 +39,7 @@ constexpr int kStepFloats = 256;   // [2 halves][32 lanes][4 blocks]
 constexpr int kW2Steps = 64;
 constexpr int kTailFloats = 260;   // b2r[128], w3r[128], b3, pad[3]
 constexpr int kHintFloats = 220;   // hint MLP (217 floats) staged in LDS behind the tail
+constexpr int kStageFloats = 256;  // per wave: 32 pixels x 8 planes of finished scores awaiting a 32-byte store
 constexpr int kMaxSrcMfma = 7;     // LDS budget: 12*K + 64 + ~1 KB <= 160 KB
 
 __host__ __device__ inline int mlp_w1dyn_floats(int K) { return K * kStepsPerView * kStepFloats; }
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   float* lds_w1 = lds;
   float* lds_w2 = lds + n_dyn;
   float* lds_tail = lds_w2 + kW2Floats;
+  float* lds_stage = lds_tail + kTailFloats + kHintFloats + (threadIdx.x >> 6) * kStageFloats;
 
   // ---- stage the weights once per workgroup ------------------------------------------------
   {
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   const int lane_off = (half * 32 + pl) * 4;  // float offset of this lane inside a step block
   const long waves_total = (long)gridDim.x * NWAVES;
   const float b3 = lds_tail[256];
+  const bool stage_ok = (D % 8 == 0);  // float4 alignment of the staged NHWC stores
 #if defined(DT_MLP_PRIO)
   // static priority for the younger half of a two-waves-per-SIMD workgroup: breaks the lock-step
   // in which both waves of a SIMD reach their gather/VALU phase together and leave the matrix pipe idle
@@ -413,11 +416,35 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         asm volatile("" ::: "memory");
         s = hint_mlp_eval_lds(lds_tail + kTailFloats, s, hint, hweight);
       }
-      if (live && half == 0) {
-        if (a.out_nhwc)
-          a.vol[((size_t)b * hw + pixi) * D + d] = s;
-        else
-          a.vol[((size_t)b * D + d) * hw + pixi] = s;
+      if (!a.out_nhwc) {
+        if (live && half == 0) a.vol[((size_t)b * D + d) * hw + pixi] = s;
+      } else if (!stage_ok) {
+        if (live && half == 0) a.vol[((size_t)b * hw + pixi) * D + d] = s;
+      } else {
+        // NHWC volume: a lane-per-pixel store writes 4 bytes every D*4 bytes (11x write amplification
+        // at the memory controller).  Park the scores of up to 8 consecutive planes in LDS and write
+        // them as one float4 per lane, i.e. 32 contiguous bytes per pixel.
+        if (half == 0) lds_stage[pl * 8 + (d & 7)] = s;
+        if ((d & 7) == 7 || d == d1 - 1) {
+          __builtin_amdgcn_wave_barrier();
+          const int cbase = d & ~7;
+          const int lo = max(d0, cbase) - cbase, hi = d - cbase;  // valid planes of this chunk: [lo, hi]
+          const int spx = lane >> 1, q = (lane & 1) * 4;
+          const float4 v4 = *reinterpret_cast<const float4*>(lds_stage + spx * 8 + q);
+          const size_t spix = (size_t)tile * 32 + spx;
+          if (spix < hw) {
+            float* dst = a.vol + ((size_t)b * hw + spix) * D + cbase + q;
+            if (lo <= q && hi >= q + 3) {
+              *reinterpret_cast<float4*>(dst) = v4;
+            } else {
+              if (lo <= q + 0 && hi >= q + 0) dst[0] = v4.x;
+              if (lo <= q + 1 && hi >= q + 1) dst[1] = v4.y;
+              if (lo <= q + 2 && hi >= q + 2) dst[2] = v4.z;
+              if (lo <= q + 3 && hi >= q + 3) dst[3] = v4.w;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
       }
     }
   }
@@ -472,8 +499,9 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
   a.num_tiles = (int)((hw + 31) / 32);
   const int cus = num_cus();
   a.total_units = (long)batch * a.num_tiles * num_planes;
-  const size_t lds_bytes = (size_t)(mlp_w1dyn_floats(num_src) + kW2Floats + kTailFloats + kHintFloats) * sizeof(float);
   const int nw = g_mlp_waves;
+  const size_t lds_bytes =
+      (size_t)(mlp_w1dyn_floats(num_src) + kW2Floats + kTailFloats + kHintFloats + nw * kStageFloats) * sizeof(float);
   const long want = (a.total_units + nw - 1) / nw;  // at least one unit per wave
   const int blocks = (int)(want < cus ? want : cus);
 #define DT_LAUNCH_MLP(HINT_, NW_)                                                                                  \
