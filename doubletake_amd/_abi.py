@@ -76,7 +76,10 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if not _build.is_current():
+    override = os.environ.get("DOUBLETAKE_HIP_LIB")  # experiment hook: load a differently-built .so
+    if override:
+        path = override
+    elif not _build.is_current():
         try:
             _build.build(verbose=False)
         except Exception as e:  # no hipcc / compile error
