@@ -91,6 +91,45 @@ def cpu_baseline_frame(inp, pyr, model):
     return time.perf_counter() - t0
 
 
+def dot_volume_roofline(device, t, launches=30):
+    """North-star side figure: the plain dot-product warp+match kernel (cv_dot_kernel, the volume of
+    CostVolumeManager) against the HBM roofline, on the same features.  Run AFTER the timed region;
+    HIP events bracket the kernel launch only.  Algorithmic bytes = inputs read once + volume written
+    once; gather bytes = what the bilinear taps really pull through L1."""
+    import torch
+    from doubletake_amd.modules import cost_volume as cvmod
+
+    h, w = CFG["image_h"] // 4, CFG["image_w"] // 4
+    b, k, D, c = CFG["batch"], CFG["num_src"], CFG["planes"], 16
+    m = cvmod.CostVolumeManager(h, w, num_depth_bins=D).to(device)
+    evs = []
+
+    def hook(tag):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(device))
+        evs.append(ev)
+
+    call = lambda: m(t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"], t["src_Ks"], t["cur_invK"],
+                     t["min_depth"], t["max_depth"])
+    for _ in range(5):
+        call()
+    cvmod.CostVolumeManager._dot_event_hook = staticmethod(hook)
+    for _ in range(launches):
+        call()
+    torch.cuda.synchronize(device)
+    cvmod.CostVolumeManager._dot_event_hook = None
+    ms = float(np.mean([evs[i].elapsed_time(evs[i + 1]) for i in range(0, len(evs), 2)]))
+    algo = 4.0 * b * h * w * (c * (k + 1) + D)
+    gather = 4.0 * b * h * w * D * k * 4 * c
+    return {
+        "kernel": "cv_dot_kernel (CostVolumeManager: warp + dot-product match, not on the DoubleTake path)",
+        "bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+        "frac": algo / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+        "algorithmic_bytes_per_launch": algo, "bilinear_gather_bytes_per_launch": gather,
+        "gather_GBps": gather / (ms * 1e-3) / 1e9, "avg_launch_ms": ms,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +301,8 @@ def main():
                 "avg_launch_ms": kern_ms,
             },
         }
+        if world == 1:
+            result["roofline_warp_match_dot"] = dot_volume_roofline(device, t)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 from threadpoolctl import threadpool_info

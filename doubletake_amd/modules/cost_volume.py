@@ -58,6 +58,8 @@ class CostVolumeManager(nn.Module):
     #: write the volume as torch.channels_last ([b,D,h,w] logical, NHWC physical); the conv
     #: stack that consumes it (CVEncoder) is NHWC.  Only honoured by the MLP volumes.
     channels_last_output = True
+    #: optional callable(tag) invoked right before / after dt_cv_dot_f32 (bench.py: HIP events)
+    _dot_event_hook = None
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, matching_dim_size=None,
                  num_source_views=None):
@@ -175,8 +177,13 @@ class CostVolumeManager(nn.Module):
             cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth, depth_planes_bdhw)
         b, k, c, h, w, D = dims
         vol = torch.empty(b, D, h, w, device=cur.device, dtype=torch.float32)
+        hook = CostVolumeManager._dot_event_hook
+        if hook is not None:
+            hook("dot_begin")
         _abi.check(L.dt_cv_dot_f32(_abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(vol), b, k, c, h, w, D,
                                    stream), "dt_cv_dot_f32")
+        if hook is not None:
+            hook("dot_end")
         low = self._lowest(L, stream, vol, params, False, dims)
         return vol, low, planes, None
 

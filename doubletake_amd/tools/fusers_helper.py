@@ -1,8 +1,6 @@
 """OurFuser with the reference's constructor and methods (reference tools/fusers_helper.py:23-107)."""
 from __future__ import annotations
 
-import struct
-
 import numpy as np
 
 from .tsdf import TSDF, TSDFFuser
@@ -68,13 +66,9 @@ class OurFuser(DepthFuser):
 
     def export_mesh(self, path, export_single_mesh=True, trim_tsdf_using_confience=False):
         _, verts, faces = self.get_mesh_pytorch3d()
-        v, f = verts.cpu().numpy(), faces.cpu().numpy().astype(np.int32)
-        with open(path, "wb") as fh:
-            fh.write((f"ply\nformat binary_little_endian 1.0\nelement vertex {len(v)}\nproperty float x\nproperty float y\n"
-                      f"property float z\nelement face {len(f)}\nproperty list uchar int vertex_indices\nend_header\n").encode())
-            fh.write(v.astype("<f4").tobytes())
-            for tri in f:
-                fh.write(struct.pack("<B3i", 3, *tri))
+        from ..utils.formats import write_ply
+
+        write_ply(path, verts.cpu().numpy(), faces.cpu().numpy())
 
     def save_tsdf(self, path):
         self.tsdf_fuser_pred.tsdf.save_tsdf(path)

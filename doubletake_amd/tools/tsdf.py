@@ -47,6 +47,40 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _recover_origin_f32(voxel_coords_3hwd, voxel_size):
+    """A saved volume only holds the half-rounded coordinate grid (reference tools/tsdf.py:267-275), while
+    the kernels regenerate coordinates as half(origin_f32 + idx * voxel_size).  Find an fp32 origin that
+    reproduces the stored grid bit for bit: every stored half value bounds origin + idx*voxel_size to its
+    rounding interval; intersect the intervals per axis, pick a point, verify by regeneration."""
+    if voxel_coords_3hwd is None:
+        raise NotImplementedError("a TSDF needs either origin_f32 or the voxel_coords_3hwd grid")
+    c = voxel_coords_3hwd.half().cpu().numpy()
+    vs = np.float32(voxel_size)
+    origin = np.zeros(3, dtype=np.float32)
+    for a in range(3):
+        line = np.moveaxis(c[a], a, 0).reshape(c.shape[1 + a], -1)
+        if not (line == line[:, :1]).all():
+            raise NotImplementedError("voxel_coords_3hwd is not an axis-aligned regular grid")
+        h = line[:, 0]
+        step = (np.arange(len(h), dtype=np.float32) * vs).astype(np.float64)  # torch: int64 index * python float -> fp32
+        up = np.nextafter(h, np.float16(np.inf)).astype(np.float64)
+        dn = np.nextafter(h, np.float16(-np.inf)).astype(np.float64)
+        hv = h.astype(np.float64)
+        lo = ((hv + dn) * 0.5 - step).max()
+        hi = ((hv + up) * 0.5 - step).min()
+        found = None
+        for frac in (0.5, 0.25, 0.75, 0.125, 0.875, 0.375, 0.625, 0.0, 1.0):
+            cand = np.float32(lo + (hi - lo) * frac)
+            regen = (cand + np.arange(len(h), dtype=np.float32) * vs).astype(np.float16)
+            if lo <= hi and np.array_equal(regen, h):
+                found = cand
+                break
+        if found is None:
+            raise NotImplementedError("voxel_coords_3hwd is not half(origin + idx*voxel_size) for any fp32 origin")
+        origin[a] = found
+    return origin
+
+
 class TSDF:
     VOX_MOD = 8
 
@@ -64,9 +98,10 @@ class TSDF:
             # the half origin is not enough to regenerate the coordinates bit-for-bit; check it
             o = self.origin.float().numpy()
             regen = self.generate_voxel_coords(torch.from_numpy(o), (X, Y, Z), self.voxel_size).half()
-            if voxel_coords_3hwd is None or not torch.equal(regen, voxel_coords_3hwd.half().cpu()):
-                raise NotImplementedError("voxel_coords_3hwd is not origin + idx*voxel_size with the stored (half) origin")
-            origin_f32 = o
+            if voxel_coords_3hwd is not None and torch.equal(regen, voxel_coords_3hwd.half().cpu()):
+                origin_f32 = o
+            else:
+                origin_f32 = _recover_origin_f32(voxel_coords_3hwd, self.voxel_size)
         self.origin_f32 = np.asarray(origin_f32, dtype=np.float32).reshape(3)
         self.voxel_bitmap = torch.zeros((X * Y * Z) // 32, dtype=torch.int32, device=dev)
         self._mc_ws = None

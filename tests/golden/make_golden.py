@@ -377,8 +377,64 @@ def gen_tsdf(ref, out):
     np.savez_compressed(os.path.join(out, "tsdf.npz"), **res)
 
 
+def gen_formats(ref, out):
+    """Files written by the reference's own writers: a saved TSDF volume, two depth-cache pickles and a
+    score sheet.  They are data fixtures for tests/test_formats.py."""
+    import shutil
+
+    import torch
+    from doubletake_amd.utils import synthetic as syn
+
+    T = ref["tsdf"]
+    from doubletake.utils import generic_utils, metrics_utils
+
+    fdir = os.path.join(out, "formats")
+    shutil.rmtree(fdir, ignore_errors=True)
+    os.makedirs(fdir)
+    bd = dict(xmin=-0.64, xmax=0.64, ymin=-0.56, ymax=0.56, zmin=0.0, zmax=1.12)
+    ts = T.TSDF.from_bounds(bd, 0.04)
+    fuser = T.TSDFFuser(ts, max_depth=3.0, use_gpu=False)
+    depth, K, Tcw = syn.tsdf_frames(2, 48, 64, seed=11, bounds=bd)
+    depth = depth * np.float32(0.35)
+    for f in range(2):
+        fuser.integrate_depth(t(depth[f:f + 1]).half(), t(Tcw[f:f + 1]).half(), t(K[f:f + 1]).half())
+    ts.save_tsdf(os.path.join(fdir, "ref_saved_tsdf.npz"))
+    np.savez_compressed(os.path.join(fdir, "ref_saved_tsdf_inputs.npz"), depth=depth, K=K, Tcw=Tcw,
+                        bounds=np.array([bd[k] for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")]))
+
+    # depth cache: batch of two keyframes
+    b, h, w = 2, 12, 16
+    outputs = {
+        "depth_pred_s0_b1hw": t(syn.hash_u01((b, 1, h, w), 21).astype(np.float32) + 0.5),
+        "overall_mask_bhw": t(syn.hash_u01((b, h, w), 22).astype(np.float32)) > 0.3,
+        "cv_confidence_b1hw": t(syn.hash_u01((b, 1, h, w), 23).astype(np.float32)),
+    }
+    eye = np.tile(np.eye(4, dtype=np.float32), (b, 1, 1))
+    cur_data = {
+        "frame_id_string": ["000012", "000031"],
+        "K_full_depth_b44": t(eye * 2.0), "K_s0_b44": t(eye * 0.5), "cam_T_world_b44": t(eye),
+    }
+    src_data = {"frame_id_string": [["000010", "000029"], ["000008", "000027"]]}
+    os.makedirs(os.path.join(fdir, "depth_cache"))
+    generic_utils.cache_model_outputs(os.path.join(fdir, "depth_cache"), outputs, cur_data, src_data, 0, b)
+    torch.save({k: v for k, v in outputs.items()}, os.path.join(fdir, "depth_cache_inputs.pt"))
+
+    # score sheet
+    avg = metrics_utils.ResultsAverager("golden_exp", "frame metrics")
+    for i in range(3):
+        gt = t(syn.hash_u01((1, 200), 31 + i).astype(np.float32) + 1.0)
+        pr = gt * t(1.0 + 0.2 * (syn.hash_u01((1, 200), 41 + i).astype(np.float32) - 0.5))
+        m = metrics_utils.compute_depth_metrics(gt, pr)
+        avg.update_results({k: float(v) for k, v in m.items()})
+    avg.compute_final_average()
+    avg.output_json(os.path.join(fdir, "ref_scores.json"))
+    np.savez(os.path.join(fdir, "ref_scores_inputs.npz"),
+             names=np.array(list(avg.final_metrics.keys())), values=np.array([float(v) for v in avg.final_metrics.values()]))
+    print("formats:", sorted(os.listdir(fdir)))
+
+
 def main():
-    which = set(sys.argv[1:]) or {"volume", "fullsize", "networks", "tsdf"}
+    which = set(sys.argv[1:]) or {"volume", "fullsize", "networks", "tsdf", "formats"}
     ref = import_reference()
     if "volume" in which:
         gen_volume(ref, OUT)
@@ -388,6 +444,8 @@ def main():
         gen_networks(ref, OUT)
     if "tsdf" in which:
         gen_tsdf(ref, OUT)
+    if "formats" in which:
+        gen_formats(ref, OUT)
 
 
 if __name__ == "__main__":
