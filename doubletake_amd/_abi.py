@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
     """struct dt_conv_desc (include/doubletake_hip.h)."""
     _fields_ = [("n", C.c_int), ("h_out", C.c_int), ("w_out", C.c_int), ("c_out", C.c_int), ("nsrc", C.c_int),
                 ("c", C.c_int * 3), ("up", C.c_int * 3), ("ksize", C.c_int), ("stride", C.c_int), ("act", C.c_int),
-                ("h_in", C.c_int), ("w_in", C.c_int)]
+                ("h_in", C.c_int), ("w_in", C.c_int), ("pad_mode", C.c_int)]
 
 
 class TsdfThresholds(C.Structure):
@@ -58,6 +58,15 @@ SIGNATURES = {
     "dt_head_mlp_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "dt_upsample2x_bilinear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dt_exp_f32": (_I, [_P, _P, _L, _P]),
+    "dt_stem_im2col_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "dt_stem_pack_floats": (_I, []),
+    "dt_stem_pack_f32": (_I, [_P, _P, _P]),
+    "dt_stem_conv_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dt_maxpool_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dt_blurpool4_s2_f32": (_I, [_P, _P, C.POINTER(_F), _I, _I, _I, _I, _P]),
+    "dt_maxblur_f32": (_I, [_P, _P, C.POINTER(_F), _I, _I, _I, _I, _P]),
+    "dt_instnorm_workspace_bytes": (_L, [_I, _I, _I]),
+    "dt_instnorm_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "dt_raster_depth_f32": (_I, [_P, _P, _L, _P, _P, _I, _I, _P, _P, _P]),
     "dt_tsdf_frame_params_floats": (_I, []),
     "dt_tsdf_frame_setup_f16": (_I, [_P, _P, _I, _I, _F, _F, _P, _P]),

@@ -32,6 +32,7 @@ struct ConvArgs {
   const float* res;
   float* out;
   int n, h_out, w_out, c_out, h_in, w_in, act;
+  int pad_replicate;  // 1: out-of-image taps read the clamped (edge) pixel instead of zero
   int groups;  // total 8-channel input groups over all sources
   int tiles_x, tiles_y, co_blocks;
 };
@@ -39,6 +40,7 @@ struct ConvArgs {
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == DT_ACT_LRELU02) return v >= 0.f ? v : 0.2f * v;
   if (act == DT_ACT_ELU) return v > 0.f ? v : __expf(v) - 1.0f;  // ATen's elu: exp(x) - 1
+  if (act == DT_ACT_RELU) return fmaxf(v, 0.f);
   return v;
 }
 
@@ -106,8 +108,13 @@ __global__ __launch_bounds__(SPLIT == 8 ? 512 : 256) void conv_mfma_kernel(const
   for (int it = 0; it < NLOAD; ++it) {
     const int idx = (lane >> 1) + it * 32;
     const int ly = idx / IW, lx = idx - ly * IW;
-    const int iy = iy0 + ly, ix = ix0 + lx;
-    const bool inside = idx < NPIX && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+    int iy = iy0 + ly, ix = ix0 + lx;
+    bool inside = idx < NPIX && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+    if (a.pad_replicate) {
+      iy = min(max(iy, 0), a.h_in - 1);
+      ix = min(max(ix, 0), a.w_in - 1);
+      inside = idx < NPIX;
+    }
     poff0[it] = pixel_offset(inside, n, iy, ix, a.h_in, a.w_in, a.up[0], a.c[0], lane);
     poff1[it] = pixel_offset(inside && a.nsrc > 1, n, iy, ix, a.h_in, a.w_in, a.up[1], a.c[1], lane);
     poff2[it] = pixel_offset(inside && a.nsrc > 2, n, iy, ix, a.h_in, a.w_in, a.up[2], a.c[2], lane);
@@ -281,8 +288,13 @@ __global__ __launch_bounds__(256) void conv_mfma_wshare_kernel(const ConvArgs a)
   for (int it = 0; it < NLOAD; ++it) {
     const int idx = (lane >> 1) + it * 32;
     const int ly = idx / IW, lx = idx - ly * IW;
-    const int iy = iy0 + ly, ix = ix0 + lx;
-    const bool inside = idx < NPIX && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+    int iy = iy0 + ly, ix = ix0 + lx;
+    bool inside = idx < NPIX && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+    if (a.pad_replicate) {
+      iy = min(max(iy, 0), a.h_in - 1);
+      ix = min(max(ix, 0), a.w_in - 1);
+      inside = idx < NPIX;
+    }
     poff0[it] = pixel_offset(inside, n, iy, ix, a.h_in, a.w_in, a.up[0], a.c[0], lane);
     poff1[it] = pixel_offset(inside && a.nsrc > 1, n, iy, ix, a.h_in, a.w_in, a.up[1], a.c[1], lane);
     poff2[it] = pixel_offset(inside && a.nsrc > 2, n, iy, ix, a.h_in, a.w_in, a.up[2], a.c[2], lane);
@@ -482,8 +494,13 @@ __global__ void conv_simple_kernel(const ConvArgs a, const float* __restrict__ W
     float acc = a.bias ? a.bias[co] : 0.f;
     for (int ky = 0; ky < ks; ++ky)
       for (int kx = 0; kx < ks; ++kx) {
-        const int iy = oy * st + ky - pad, ix = ox * st + kx - pad;
-        if (iy < 0 || iy >= a.h_in || ix < 0 || ix >= a.w_in) continue;
+        int iy = oy * st + ky - pad, ix = ox * st + kx - pad;
+        if (a.pad_replicate) {
+          iy = min(max(iy, 0), a.h_in - 1);
+          ix = min(max(ix, 0), a.w_in - 1);
+        } else if (iy < 0 || iy >= a.h_in || ix < 0 || ix >= a.w_in) {
+          continue;
+        }
         int cbase = 0;
         for (int s = 0; s < a.nsrc; ++s) {
           const int up = a.up[s];
@@ -561,7 +578,8 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
   DT_REQUIRE(d->ksize == 1 || d->ksize == 3, "%s: ksize=%d (1 or 3)", who, d->ksize);
   DT_REQUIRE(d->stride == 1 || d->stride == 2, "%s: stride=%d (1 or 2)", who, d->stride);
   DT_REQUIRE(!(d->ksize == 1 && d->stride == 2), "%s: 1x1 stride-2 conv is not used by the reference", who);
-  DT_REQUIRE(d->act >= 0 && d->act <= 2, "%s: act=%d", who, d->act);
+  DT_REQUIRE(d->act >= 0 && d->act <= 3, "%s: act=%d", who, d->act);
+  DT_REQUIRE(d->pad_mode == 0 || d->pad_mode == 1, "%s: pad_mode=%d (0 zeros, 1 replicate)", who, d->pad_mode);
   const int pad = d->ksize / 2;
   DT_REQUIRE(d->h_out == (d->h_in + 2 * pad - d->ksize) / d->stride + 1 &&
                  d->w_out == (d->w_in + 2 * pad - d->ksize) / d->stride + 1,
@@ -595,6 +613,7 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
   a.h_in = d->h_in;
   a.w_in = d->w_in;
   a.act = d->act;
+  a.pad_replicate = d->pad_mode;
   a.tiles_x = (d->w_out + kPW - 1) / kPW;
   a.tiles_y = (d->h_out + kPH - 1) / kPH;
   a.co_blocks = d->c_out / 32;

@@ -55,7 +55,7 @@ using namespace dt;
 
 extern "C" {
 
-int dt_version(void) { return 100; }
+int dt_version(void) { return 101; }
 
 const char* dt_last_error(void) { return err_buf(); }
 

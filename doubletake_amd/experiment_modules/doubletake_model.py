@@ -2,13 +2,13 @@
 
 The reference's forward (:265-425) is
     image encoder (timm) -> matching encoder -> cost volume -> CVEncoder -> decoder -> exp
-The first two are ordinary PyTorch-ROCm conv stacks and stay outside this package (north star:
-"PyTorch-ROCm for the ordinary 2D conv stacks").  ``DepthModelCVHint`` here owns the three
-modules the HIP kernels replace, under the reference's attribute names so a reference
-checkpoint's ``cost_volume.* / cost_volume_net.* / depth_decoder.*`` keys load unchanged, and
-exposes ``forward_from_features`` = lines :341-349 and :375-423 of the reference forward.
-Encoders can be attached as ``self.encoder`` / ``self.matching_model`` (any nn.Module producing
-the reference's feature shapes) to run the whole ``forward``.
+The image encoder is a third-party timm network and stays outside this package (north star:
+"PyTorch-ROCm for the ordinary 2D conv stacks").  ``DepthModelCVHint`` here owns the modules the
+HIP kernels replace, under the reference's attribute names so a reference checkpoint's
+``matching_model.* / cost_volume.* / cost_volume_net.* / depth_decoder.*`` keys load unchanged, and
+exposes ``compute_matching_feats`` (:206-262) and ``forward_from_features`` = lines :341-349 and
+:375-423 of the reference forward.  An image encoder can be attached as ``self.encoder`` (any
+nn.Module producing the reference's five feature maps) to run the whole ``forward``.
 """
 from __future__ import annotations
 
@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from ..modules import conv_ops as ops
 from ..modules.cost_volume import FeatureMeshHintVolumeManager
-from ..modules.networks import CVEncoder, DepthDecoderPP
+from ..modules.networks import CVEncoder, DepthDecoderPP, ResnetMatchingEncoder
 from ..modules.networks_fast import SkipDecoderRegression
 
 #: channel widths of the timm image encoders the reference uses (doubletake_model.py:121-130)
@@ -27,7 +27,7 @@ ENCODER_WIDTHS = {"resnet18d": [64, 64, 128, 256, 512], "efficientnet": [24, 48,
 class DepthModelCVHint(nn.Module):
     def __init__(self, image_height=384, image_width=512, image_encoder_name="resnet18d", depth_decoder_name="skip",
                  matching_num_depth_bins=64, matching_scale=1, matching_feature_dims=16, model_num_views=8,
-                 min_matching_depth=0.25, max_matching_depth=5.0):
+                 min_matching_depth=0.25, max_matching_depth=5.0, matching_encoder_type="resnet"):
         super().__init__()
         key = "efficientnet" if "efficientnet" in image_encoder_name else "resnet18d"
         self.num_ch_enc = list(ENCODER_WIDTHS[key])
@@ -49,7 +49,28 @@ class DepthModelCVHint(nn.Module):
             num_depth_bins=matching_num_depth_bins, matching_dim_size=matching_feature_dims,
             num_source_views=model_num_views - 1)
         self.encoder = None
-        self.matching_model = None
+        if matching_encoder_type == "resnet":  # doubletake_model.py:196-197
+            self.matching_model = ResnetMatchingEncoder(18, matching_feature_dims, pretrained=False)
+        elif matching_encoder_type is None:
+            self.matching_model = None
+        else:
+            raise ValueError(f"Unrecognized option {matching_encoder_type} for matching encoder type!")
+
+    @torch.no_grad()
+    def compute_matching_feats(self, cur_image, src_image, unbatched_matching_encoder_forward=False):
+        """doubletake_model.py:206-262: matching features of the current image [b,3,H,W] and the source
+        images [b,K,3,H,W] -> ([b,C,h,w], [b,K,C,h,w]).  Batched: all b*(1+K) images in one pass."""
+        if self.matching_model is None:
+            raise RuntimeError("this model was built without a matching encoder")
+        frames = torch.cat([cur_image.unsqueeze(1), src_image], dim=1)
+        b, m = frames.shape[:2]
+        flat = frames.flatten(0, 1)
+        if unbatched_matching_encoder_forward:
+            feats = torch.cat([self.matching_model(f) for f in flat.split(1, dim=0)], dim=0)
+        else:
+            feats = self.matching_model(flat)
+        feats = feats.view(b, m, *feats.shape[1:])
+        return feats[:, 0], feats[:, 1:].contiguous()
 
     @torch.no_grad()
     def forward_from_features(self, cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
@@ -82,18 +103,16 @@ class DepthModelCVHint(nn.Module):
 
     @torch.no_grad()
     def forward(self, phase, cur_data, src_data, unbatched_matching_encoder_forward=False, return_mask=False):
-        """Reference signature (doubletake_model.py:265).  Needs self.encoder / self.matching_model."""
-        if self.encoder is None or self.matching_model is None:
-            raise RuntimeError("attach .encoder and .matching_model (PyTorch-ROCm modules) or call forward_from_features")
+        """Reference signature (doubletake_model.py:265).  Needs self.encoder (the timm image encoder)."""
+        if self.encoder is None:
+            raise RuntimeError("attach .encoder (the image-prior network, a PyTorch-ROCm module) or call forward_from_features")
         s = self.matching_scale
         src_K = src_data[f"K_s{s}_b44"]
         cur_invK = cur_data[f"invK_s{s}_b44"]
         src_cam_T_cur_cam = src_data["cam_T_world_b44"] @ cur_data["world_T_cam_b44"].unsqueeze(1)
         cur_cam_T_src_cam = cur_data["cam_T_world_b44"].unsqueeze(1) @ src_data["world_T_cam_b44"]
         cur_feats = self.encoder(cur_data["image_b3hw"])
-        b, k = src_data["image_b3hw"].shape[:2]
-        m_cur = self.matching_model(cur_data["image_b3hw"])
-        m_src = self.matching_model(src_data["image_b3hw"].flatten(0, 1))
-        m_src = m_src.view(b, k, *m_src.shape[1:])
+        m_cur, m_src = self.compute_matching_feats(cur_data["image_b3hw"], src_data["image_b3hw"],
+                                                   unbatched_matching_encoder_forward)
         return self.forward_from_features(cur_feats, m_cur, m_src, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K,
                                           cur_invK, cur_data, return_mask=return_mask)

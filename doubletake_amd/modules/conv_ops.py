@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from .. import _abi
 
-ACT_NONE, ACT_LRELU02, ACT_ELU = 0, 1, 2
+ACT_NONE, ACT_LRELU02, ACT_ELU, ACT_RELU = 0, 1, 2, 3
 
 
 def _require_gpu(t, name="input"):
@@ -56,7 +56,7 @@ def packed_weight(conv: nn.Conv2d, device):
         return hit[1]
     co, ci, k, k2 = w.shape
     if (k != k2 or conv.groups != 1 or conv.dilation != (1, 1) or conv.padding != (k // 2, k // 2)
-            or conv.padding_mode != "zeros"):
+            or conv.padding_mode not in ("zeros", "replicate")):
         raise NotImplementedError(f"unsupported conv configuration {conv}")
     L = _abi.lib()
     wd = w.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -102,6 +102,7 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
     d = _abi.ConvDesc()
     d.n, d.c_out, d.nsrc, d.ksize, d.stride, d.act = n, co, len(srcs), k, st, act
     d.h_in, d.w_in = h_in, w_in
+    d.pad_mode = 1 if conv.padding_mode == "replicate" else 0
     pad = k // 2
     d.h_out = (h_in + 2 * pad - k) // st + 1
     d.w_out = (w_in + 2 * pad - k) // st + 1

@@ -36,6 +36,7 @@ import torch  # noqa: E402
 
 from . import conv_ops as ops  # noqa: E402
 from .layers import BasicBlock  # noqa: E402
+from .matching_encoder import ResnetMatchingEncoder  # noqa: E402,F401
 
 
 def double_basic_block(num_ch_in, num_ch_out, num_repeats=2):

@@ -116,7 +116,7 @@ int dt_cv_overall_mask_u8(const float* params, uint8_t* mask_out, int per_view, 
  * ConvBlock / ConvUpsampleAndConcatBlock (modules/networks_fast.py:17-40).
  * Weights are pre-packed by doubletake_amd.modules.conv_pack (dt_conv_pack_floats).
  */
-enum { DT_ACT_NONE = 0, DT_ACT_LRELU02 = 1, DT_ACT_ELU = 2 };
+enum { DT_ACT_NONE = 0, DT_ACT_LRELU02 = 1, DT_ACT_ELU = 2, DT_ACT_RELU = 3 };
 
 typedef struct dt_conv_desc {
   int n, h_out, w_out;      /* output extent */
@@ -128,6 +128,7 @@ typedef struct dt_conv_desc {
   int stride;               /* 1 or 2 */
   int act;                  /* DT_ACT_* */
   int h_in, w_in;           /* extent of the (virtual, post-upsample) input */
+  int pad_mode;             /* 0: zero padding; 1: replicate (nn.Conv2d padding_mode="replicate") */
 } dt_conv_desc;
 
 int64_t dt_conv_pack_floats(int c_out, int c_in, int ksize);
@@ -159,6 +160,37 @@ int dt_upsample2x_bilinear_f32(const float* in_nhwc, float* out_nhwc, int n, int
                                int c, dt_stream_t s);
 /* exp() of the log-depth heads (experiment_modules/doubletake_model.py:410-418). */
 int dt_exp_f32(const float* in, float* out, int64_t count, dt_stream_t s);
+
+/* ---- matching encoder (next row of the path: modules/networks.py:138-189) -----------------
+ * The convolutions run on dt_conv2d_f32 (BatchNorm folded into weight/bias on the host, ReLU as
+ * DT_ACT_RELU, the final 3x3 with pad_mode = 1); these are the ops between them.  NHWC fp32. */
+/* 7x7 stride-2 pad-3 stem conv as im2col: image NCHW [n,3,H,W] -> cols [n,Ho,Wo,152] with column
+ * ci*49+ky*7+kx (= weight.reshape(c_out,-1) order), columns 147..151 zero; Ho=(H-1)/2+1. */
+int dt_stem_im2col_f32(const float* image_nchw, float* cols_nhwc, int n, int H, int W, dt_stream_t s);
+/* The same conv fused (no im2col buffer): image NCHW [n,3,H,W] -> out NHWC [n,Ho,Wo,64] with bias
+ * (folded BatchNorm) and DT_ACT_RELU/NONE.  packed_w: dt_stem_pack_floats() floats made by
+ * dt_stem_pack_f32 from the [64,3,7,7] weight (device pointers). */
+int dt_stem_pack_floats(void);
+int dt_stem_pack_f32(const float* W_64x3x7x7, float* packed, dt_stream_t s);
+int dt_stem_conv_f32(const float* image_nchw, const float* packed_w, const float* bias64,
+                     float* out_nhwc, int n, int H, int W, int act, dt_stream_t s);
+/* nn.MaxPool2d(ksize, stride, pad) (torchvision resnet: 3,2,1; anti-aliased resnet: 2,1,0). */
+int dt_maxpool_f32(const float* in_nhwc, float* out_nhwc, int n, int h, int w, int c, int ksize,
+                   int stride, int pad, dt_stream_t s);
+/* BlurPool(filt_size=4, stride=2, reflect pad (1,2,1,2)) of anti-aliased ResNets: depthwise 4x4
+ * filter filt16 (HOST pointer, row-major; the module's `filt` buffer), ho=(h-1)/2+1. */
+int dt_blurpool4_s2_f32(const float* in_nhwc, float* out_nhwc, const float* filt16_host, int n, int h,
+                        int w, int c, dt_stream_t s);
+/* MaxPool2d(2, stride 1) followed by that BlurPool, fused (one read of the input):
+ * in [n,h,w,c] -> out [n,(h-2)/2+1,(w-2)/2+1,c]. */
+int dt_maxblur_f32(const float* in_nhwc, float* out_nhwc, const float* filt16_host, int n, int h,
+                   int w, int c, dt_stream_t s);
+/* nn.InstanceNorm2d(c) (affine=False, biased variance) + optional LeakyReLU(0.2).  in NHWC with
+ * c_stride >= c floats per pixel (only the first c are normalised); out [n,hw,c] or, with
+ * out_nchw, [n,c,hw].  workspace: dt_instnorm_workspace_bytes(n,hw,c) device bytes. */
+int64_t dt_instnorm_workspace_bytes(int n, int hw, int c);
+int dt_instnorm_f32(const float* in_nhwc, float* out, void* workspace, int n, int hw, int c,
+                    int c_stride, float eps, int act, int out_nchw, dt_stream_t s);
 
 /* ---- TSDF fusion -----------------------------------------------------------------------
  * Volume: values/weights fp16 [X,Y,Z] (Z fastest), voxel (i,j,k) centre =

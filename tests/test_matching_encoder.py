@@ -1,0 +1,164 @@
+"""ResnetMatchingEncoder: state-dict layout (CPU) and GPU parity against the torch CPU reference."""
+import numpy as np
+import pytest
+import torch
+
+from doubletake_amd.utils import synthetic as syn
+
+REF_KEYS_TAIL = ["net.5.weight", "net.5.bias", "net.8.weight", "net.8.bias"]
+
+
+def _block_keys(p):
+    out = []
+    for c, b in (("conv1", "bn1"), ("conv2", "bn2")):
+        out.append(f"{p}.{c}.weight")
+        out += [f"{p}.{b}.{n}" for n in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")]
+    return out
+
+
+def _expected_keys(antialiased):
+    keys = ["net.0.weight"] + [f"net.1.{n}" for n in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")]
+    if antialiased:
+        keys.append("net.3.1.filt")
+    return keys + _block_keys("net.4.0") + _block_keys("net.4.1") + REF_KEYS_TAIL
+
+
+def _fill(m, seed):
+    """Deterministic weights; BatchNorm statistics away from the identity so that folding is exercised."""
+    from doubletake_amd.utils.synthetic import formula_params
+
+    with torch.no_grad():
+        named = [(n, p) for n, p in m.named_parameters()]
+        for (n, p), a in zip(named, formula_params([tuple(p.shape) for _, p in named], seed)):
+            p.copy_(torch.from_numpy(a))
+        j = 0
+        for n, b in m.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(torch.from_numpy(syn.hash_normalish(tuple(b.shape), seed + 100 + j) * 0.2))
+            elif n.endswith("running_var"):
+                b.copy_(torch.from_numpy(0.5 + syn.hash_u01(tuple(b.shape), seed + 200 + j).astype(np.float32)))
+            j += 1
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.copy_(torch.from_numpy(0.8 + 0.4 * syn.hash_u01((mod.num_features,), seed + 300 + j).astype(np.float32)))
+                mod.bias.copy_(torch.from_numpy(0.1 * syn.hash_normalish((mod.num_features,), seed + 400 + j)))
+                j += 1
+    return m
+
+
+@pytest.mark.parametrize("antialiased", [True, False])
+def test_state_dict_layout_matches_reference_children(antialiased):
+    from doubletake_amd.modules.networks import ResnetMatchingEncoder
+
+    m = ResnetMatchingEncoder(18, 16, pretrained=False, antialiased=antialiased)
+    sd = m.state_dict()
+    assert list(sd.keys()) == _expected_keys(antialiased)
+    assert tuple(sd["net.0.weight"].shape) == (64, 3, 7, 7)
+    assert tuple(sd["net.5.weight"].shape) == (128, 64, 1, 1)
+    assert tuple(sd["net.8.weight"].shape) == (16, 128, 3, 3)
+    assert m.net[8].padding_mode == "replicate"
+    if antialiased:
+        f = sd["net.3.1.filt"]
+        assert tuple(f.shape) == (64, 1, 4, 4) and abs(float(f[0].sum()) - 1.0) < 1e-6
+        assert torch.allclose(f[0, 0, 0] * 64, torch.tensor([1.0, 3.0, 3.0, 1.0]))
+
+
+class _TorchBlock(torch.nn.Module):
+    """BasicBlock(64, 64) as torchvision writes it, for the module-vs-functional oracle check below."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False)
+        self.bn1 = torch.nn.BatchNorm2d(64)
+        self.conv2 = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False)
+        self.bn2 = torch.nn.BatchNorm2d(64)
+
+    def forward(self, x):
+        y = torch.relu(self.bn1(self.conv1(x)))
+        return torch.relu(self.bn2(self.conv2(y)) + x)
+
+
+def test_oracle_against_torch_modules():
+    """The functional oracle equals an nn.Sequential of torch layers (torchvision-style stem) that loads
+    the same state dict."""
+    from doubletake_amd.modules.networks import ResnetMatchingEncoder
+    from oracle import matching_encoder_ref as mref
+
+    nn = torch.nn
+    m = _fill(ResnetMatchingEncoder(18, 16, pretrained=False, antialiased=False), 5)
+    net = nn.Sequential(
+        nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1),
+        nn.Sequential(_TorchBlock(), _TorchBlock()), nn.Conv2d(64, 128, 1), nn.InstanceNorm2d(128), nn.LeakyReLU(0.2),
+        nn.Conv2d(128, 16, 3, padding=1, padding_mode="replicate"), nn.InstanceNorm2d(16)).eval()
+    net.load_state_dict({k[len("net."):]: v for k, v in m.state_dict().items()})
+    img = syn.hash_normalish((2, 3, 32, 48), 9)
+    with torch.no_grad():
+        want = net(torch.from_numpy(img)).numpy()
+    got = mref.matching_encoder(img, m.state_dict(), antialiased=False)
+    assert np.abs(got - want).max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("antialiased,shape", [(True, (2, 3, 64, 96)), (False, (2, 3, 64, 96)), (True, (1, 3, 52, 76))])
+def test_encoder_vs_cpu_reference(antialiased, shape):
+    import gpu_util as gu
+    from doubletake_amd.modules.networks import ResnetMatchingEncoder
+    from oracle import matching_encoder_ref as mref
+
+    m = _fill(ResnetMatchingEncoder(18, 16, pretrained=False, antialiased=antialiased), 7)
+    img = syn.hash_normalish(shape, 11)
+    want = mref.matching_encoder(img, m.state_dict(), antialiased=antialiased)
+    md = m.to(gu.dev())
+    got = md(torch.from_numpy(img).to(gu.dev()))
+    assert tuple(got.shape) == want.shape and got.is_contiguous()
+    # instance-normalised outputs are O(1); fp32 MFMA sums vs ATen's CPU convs
+    assert np.abs(got.cpu().numpy() - want).max() < 3e-4
+    got_simple = md(torch.from_numpy(img).to(gu.dev()), _impl="simple")
+    assert np.abs(got_simple.cpu().numpy() - want).max() < 3e-4
+    nhwc = md(torch.from_numpy(img).to(gu.dev()), channels_last_output=True)
+    assert torch.equal(nhwc.contiguous(), got)
+
+
+@pytest.mark.gpu
+def test_encoder_ops_vs_torch():
+    import torch.nn.functional as F
+
+    import gpu_util as gu
+    from doubletake_amd.modules import conv_ops as ops
+    from doubletake_amd.modules import matching_encoder as me
+
+    x = torch.from_numpy(syn.hash_normalish((2, 64, 23, 31), 3))
+    xd = ops.as_nhwc(x.to(gu.dev()))
+    for k, s, p in ((3, 2, 1), (2, 1, 0)):
+        assert torch.equal(me.maxpool(xd, k, s, p).cpu().contiguous(), F.max_pool2d(x, k, s, p))
+    blur = me.BlurPool(64)
+    want = F.conv2d(F.pad(x, (1, 2, 1, 2), mode="reflect"), blur.filt, stride=2, groups=64)
+    assert (me.blurpool(xd, blur).cpu() - want).abs().max() < 1e-6
+    want2 = F.conv2d(F.pad(F.max_pool2d(x, 2, 1), (1, 2, 1, 2), mode="reflect"), blur.filt, stride=2, groups=64)
+    got2 = me.maxblur(xd, blur).cpu()
+    assert got2.shape == want2.shape and (got2 - want2).abs().max() < 1e-6
+    for c, act in ((64, ops.ACT_LRELU02), (16, ops.ACT_NONE)):
+        want = F.instance_norm(x[:, :c], eps=1e-5)
+        if act:
+            want = F.leaky_relu(want, 0.2)
+        got = me.instance_norm(xd, c, 1e-5, act=act, out_nchw=True)
+        assert (got.cpu() - want).abs().max() < 2e-5
+        got2 = me.instance_norm(xd, c, 1e-5, act=act, out_nchw=False)
+        assert torch.equal(got2.contiguous(), got)
+
+
+@pytest.mark.gpu
+def test_replicate_padding_and_relu_conv():
+    import torch.nn.functional as F
+
+    import gpu_util as gu
+    from doubletake_amd.modules import conv_ops as ops
+
+    conv = torch.nn.Conv2d(16, 32, 3, padding=1, padding_mode="replicate")
+    x = torch.from_numpy(syn.hash_normalish((1, 16, 13, 21), 4))
+    with torch.no_grad():
+        want = F.relu(conv(x))
+    cd = conv.to(gu.dev())
+    for impl in ("mfma", "simple"):
+        got = ops.conv2d([(ops.as_nhwc(x.to(gu.dev())), False)], cd, act=ops.ACT_RELU, impl=impl)
+        assert (got.cpu() - want).abs().max() < 2e-5, impl
