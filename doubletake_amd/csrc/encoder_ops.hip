@@ -125,21 +125,51 @@ __global__ __launch_bounds__(256) void maxblur_kernel(const float* __restrict__ 
     const int b = (int)(r / ho);
     const float* base = in + (size_t)b * h * w * c + cq * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int y0 = oy * 2 - 1, x0 = ox * 2 - 1;
+    if (y0 >= 0 && y0 + 3 < hm && x0 >= 0 && x0 + 3 < wm) {
+      // interior: the 4x4 window of 2x2 maxima comes from a 5x5 input window, walked row by row
+      float4 prev[4];
 #pragma unroll
-    for (int ky = 0; ky < 4; ++ky) {
-      const int my = reflect(oy * 2 + ky - 1, hm);
+      for (int r = 0; r < 5; ++r) {
+        const float* rp = base + ((size_t)(y0 + r) * w + x0) * c;
+        float4 v[5];
 #pragma unroll
-      for (int kx = 0; kx < 4; ++kx) {
-        const int mx = reflect(ox * 2 + kx - 1, wm);
-        const float4 a = *reinterpret_cast<const float4*>(base + ((size_t)my * w + mx) * c);
-        const float4 bq = *reinterpret_cast<const float4*>(base + ((size_t)my * w + mx + 1) * c);
-        const float4 cq4 = *reinterpret_cast<const float4*>(base + ((size_t)(my + 1) * w + mx) * c);
-        const float4 d = *reinterpret_cast<const float4*>(base + ((size_t)(my + 1) * w + mx + 1) * c);
-        const float g = filt.f[ky * 4 + kx];
-        acc.x += fmaxf(fmaxf(a.x, bq.x), fmaxf(cq4.x, d.x)) * g;
-        acc.y += fmaxf(fmaxf(a.y, bq.y), fmaxf(cq4.y, d.y)) * g;
-        acc.z += fmaxf(fmaxf(a.z, bq.z), fmaxf(cq4.z, d.z)) * g;
-        acc.w += fmaxf(fmaxf(a.w, bq.w), fmaxf(cq4.w, d.w)) * g;
+        for (int q = 0; q < 5; ++q) v[q] = *reinterpret_cast<const float4*>(rp + (size_t)q * c);
+        float4 hm4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          hm4[q] = make_float4(fmaxf(v[q].x, v[q + 1].x), fmaxf(v[q].y, v[q + 1].y), fmaxf(v[q].z, v[q + 1].z),
+                               fmaxf(v[q].w, v[q + 1].w));
+        if (r > 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float g = filt.f[(r - 1) * 4 + q];
+            acc.x += fmaxf(prev[q].x, hm4[q].x) * g;
+            acc.y += fmaxf(prev[q].y, hm4[q].y) * g;
+            acc.z += fmaxf(prev[q].z, hm4[q].z) * g;
+            acc.w += fmaxf(prev[q].w, hm4[q].w) * g;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) prev[q] = hm4[q];
+      }
+    } else {
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky) {
+        const int my = reflect(y0 + ky, hm);
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          const int mx = reflect(x0 + kx, wm);
+          const float4 a = *reinterpret_cast<const float4*>(base + ((size_t)my * w + mx) * c);
+          const float4 bq = *reinterpret_cast<const float4*>(base + ((size_t)my * w + mx + 1) * c);
+          const float4 cq4 = *reinterpret_cast<const float4*>(base + ((size_t)(my + 1) * w + mx) * c);
+          const float4 d = *reinterpret_cast<const float4*>(base + ((size_t)(my + 1) * w + mx + 1) * c);
+          const float g = filt.f[ky * 4 + kx];
+          acc.x += fmaxf(fmaxf(a.x, bq.x), fmaxf(cq4.x, d.x)) * g;
+          acc.y += fmaxf(fmaxf(a.y, bq.y), fmaxf(cq4.y, d.y)) * g;
+          acc.z += fmaxf(fmaxf(a.z, bq.z), fmaxf(cq4.z, d.z)) * g;
+          acc.w += fmaxf(fmaxf(a.w, bq.w), fmaxf(cq4.w, d.w)) * g;
+        }
       }
     }
     *reinterpret_cast<float4*>(out + idx * 4) = acc;
@@ -151,7 +181,7 @@ __global__ __launch_bounds__(256) void maxblur_kernel(const float* __restrict__ 
 // partials per (image, channel), normalises, applies the optional LeakyReLU(0.2) and writes NHWC or NCHW.
 // The input may carry more channels per pixel (c_stride) than are normalised (c): the 16-channel final
 // conv is computed as a zero-padded 32-channel block.
-constexpr int kNormChunk = 256;  // pixels per pass-1 workgroup
+constexpr int kNormChunk = 64;  // pixels per pass-1 workgroup
 __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __restrict__ in, double* __restrict__ part,
                                                               int hw, int c, int c_stride, int chunks) {
   // thread t: channel t % c, pixel phase t / c; requires c <= 256 and 256 % c == 0
@@ -209,20 +239,35 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const double* __
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ in, const float* __restrict__ stats,
                                                             float* __restrict__ out, int nimg, int hw, int c, int c_stride,
                                                             int act, int out_nchw) {
+  if (!out_nchw) {
+    // NHWC -> NHWC: one float4 (4 channels of one pixel) per thread
+    const int c4 = c >> 2;
+    const size_t total = (size_t)nimg * hw * c4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+      const int cq = (int)(idx % c4);
+      const size_t pix = idx / c4;
+      const int b = (int)(pix / hw);
+      const float4 x = *reinterpret_cast<const float4*>(in + pix * c_stride + cq * 4);
+      const float4 s0 = *reinterpret_cast<const float4*>(stats + ((size_t)b * c + cq * 4) * 2);
+      const float4 s1 = *reinterpret_cast<const float4*>(stats + ((size_t)b * c + cq * 4) * 2 + 4);
+      float4 v = make_float4((x.x - s0.x) * s0.y, (x.y - s0.z) * s0.w, (x.z - s1.x) * s1.y, (x.w - s1.z) * s1.w);
+      if (act == DT_ACT_LRELU02) {
+        v.x = v.x >= 0.f ? v.x : 0.2f * v.x;
+        v.y = v.y >= 0.f ? v.y : 0.2f * v.y;
+        v.z = v.z >= 0.f ? v.z : 0.2f * v.z;
+        v.w = v.w >= 0.f ? v.w : 0.2f * v.w;
+      }
+      *reinterpret_cast<float4*>(out + pix * c + cq * 4) = v;
+    }
+    return;
+  }
+  // NHWC -> NCHW: idx enumerates the OUTPUT (coalesced stores, strided L2-resident loads)
   const size_t total = (size_t)nimg * hw * c;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    int ch, p, b;
-    if (out_nchw) {  // idx enumerates the OUTPUT: coalesced stores, strided (L2-resident) loads
-      p = (int)(idx % hw);
-      const size_t r = idx / hw;
-      ch = (int)(r % c);
-      b = (int)(r / c);
-    } else {
-      ch = (int)(idx % c);
-      const size_t r = idx / c;
-      p = (int)(r % hw);
-      b = (int)(r / hw);
-    }
+    const int p = (int)(idx % hw);
+    const size_t r = idx / hw;
+    const int ch = (int)(r % c);
+    const int b = (int)(r / c);
     const float mean = stats[((size_t)b * c + ch) * 2], inv = stats[((size_t)b * c + ch) * 2 + 1];
     float v = (in[((size_t)b * hw + p) * c_stride + ch] - mean) * inv;
     if (act == DT_ACT_LRELU02) v = v >= 0.f ? v : 0.2f * v;
@@ -296,7 +341,8 @@ int dt_instnorm_f32(const float* in, float* out, void* workspace, int n, int hw,
                     int out_nchw, dt_stream_t s) {
   DT_REQUIRE(in && out && workspace, "dt_instnorm_f32: null pointer");
   DT_REQUIRE(n > 0 && hw > 0 && c > 0 && c <= 256 && 256 % c == 0, "dt_instnorm_f32: c=%d must divide 256", c);
-  DT_REQUIRE(c_stride >= c, "dt_instnorm_f32: c_stride=%d < c=%d", c_stride, c);
+  DT_REQUIRE(c_stride >= c && c % 4 == 0 && c_stride % 4 == 0, "dt_instnorm_f32: c_stride=%d / c=%d (multiples of 4, stride >= c)",
+             c_stride, c);
   DT_REQUIRE(act == DT_ACT_NONE || act == DT_ACT_LRELU02, "dt_instnorm_f32: act=%d", act);
   const int chunks = (hw + kNormChunk - 1) / kNormChunk;
   double* part = reinterpret_cast<double*>(workspace);
@@ -304,7 +350,7 @@ int dt_instnorm_f32(const float* in, float* out, void* workspace, int n, int hw,
   hipStream_t st = to_stream(s);
   hipLaunchKernelGGL(instnorm_partial_kernel, dim3(chunks, n), dim3(256), 0, st, in, part, hw, c, c_stride, chunks);
   hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((n * c + 3) / 4), dim3(256), 0, st, part, stats, n, hw, c, chunks, eps);
-  const size_t total = (size_t)n * hw * c;
+  const size_t total = out_nchw ? (size_t)n * hw * c : (size_t)n * hw * (c / 4);
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, stats, out, n, hw, c, c_stride, act,
                      out_nchw);
   return check_launch("dt_instnorm_f32");

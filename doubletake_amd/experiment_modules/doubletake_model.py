@@ -24,6 +24,40 @@ from ..modules.networks_fast import SkipDecoderRegression
 ENCODER_WIDTHS = {"resnet18d": [64, 64, 128, 256, 512], "efficientnet": [24, 48, 64, 160, 256]}
 
 
+class MatchingFeatureCache:
+    """LRU map frame id -> matching feature map [C,h,w] (device tensor).  At 640x480 one entry is 1.2 MB, so
+    the default capacity (8192 keyframes, 10 GB) holds any ScanNet scan many times over in 288 GB of HBM."""
+
+    def __init__(self, capacity=8192):
+        from collections import OrderedDict
+
+        self.capacity = capacity
+        self._store = OrderedDict()
+        self.hits = 0
+        self.misses = 0
+
+    def __contains__(self, fid):
+        return fid in self._store
+
+    def __len__(self):
+        return len(self._store)
+
+    def get(self, fid):
+        self._store.move_to_end(fid)
+        self.hits += 1
+        return self._store[fid]
+
+    def put(self, fid, feat):
+        self.misses += 1
+        self._store[fid] = feat
+        self._store.move_to_end(fid)
+        while len(self._store) > self.capacity:
+            self._store.popitem(last=False)
+
+    def clear(self):
+        self._store.clear()
+
+
 class DepthModelCVHint(nn.Module):
     def __init__(self, image_height=384, image_width=512, image_encoder_name="resnet18d", depth_decoder_name="skip",
                  matching_num_depth_bins=64, matching_scale=1, matching_feature_dims=16, model_num_views=8,
@@ -49,6 +83,7 @@ class DepthModelCVHint(nn.Module):
             num_depth_bins=matching_num_depth_bins, matching_dim_size=matching_feature_dims,
             num_source_views=model_num_views - 1)
         self.encoder = None
+        self.matching_feature_cache = MatchingFeatureCache()
         if matching_encoder_type == "resnet":  # doubletake_model.py:196-197
             self.matching_model = ResnetMatchingEncoder(18, matching_feature_dims, pretrained=False)
         elif matching_encoder_type is None:
@@ -57,15 +92,37 @@ class DepthModelCVHint(nn.Module):
             raise ValueError(f"Unrecognized option {matching_encoder_type} for matching encoder type!")
 
     @torch.no_grad()
-    def compute_matching_feats(self, cur_image, src_image, unbatched_matching_encoder_forward=False):
+    def compute_matching_feats(self, cur_image, src_image, unbatched_matching_encoder_forward=False, cur_ids=None,
+                               src_ids=None):
         """doubletake_model.py:206-262: matching features of the current image [b,3,H,W] and the source
-        images [b,K,3,H,W] -> ([b,C,h,w], [b,K,C,h,w]).  Batched: all b*(1+K) images in one pass."""
+        images [b,K,3,H,W] -> ([b,C,h,w], [b,K,C,h,w]).  Batched: all b*(1+K) images in one pass.
+
+        Extension ("cross-frame feature caching"): with ``cur_ids`` (b frame-id strings)
+        and ``src_ids`` (K lists of b strings, the layout of ``src_data["frame_id_string"]``) features are
+        kept in an HBM-resident LRU cache and only frames not seen before go through the encoder -- in a
+        scan every keyframe is encoded once instead of once per tuple it appears in.  Features of a cached
+        frame were computed in a different batch, so they can differ from the batched result in the last
+        bits (different K-split of the same fp32 sums), exactly like the reference's unbatched flag."""
         if self.matching_model is None:
             raise RuntimeError("this model was built without a matching encoder")
         frames = torch.cat([cur_image.unsqueeze(1), src_image], dim=1)
         b, m = frames.shape[:2]
         flat = frames.flatten(0, 1)
-        if unbatched_matching_encoder_forward:
+        if cur_ids is not None and src_ids is not None:
+            ids = [[cur_ids[i]] + [src_ids[k][i] for k in range(m - 1)] for i in range(b)]
+            flat_ids = [fid for row in ids for fid in row]
+            cache = self.matching_feature_cache
+            missing = [j for j, fid in enumerate(flat_ids) if fid not in cache]
+            first = {}
+            for j in missing:  # the same new frame may appear twice in one batch
+                first.setdefault(flat_ids[j], j)
+            todo = sorted(first.values())
+            if todo:
+                new = self.matching_model(flat[todo])
+                for row, j in enumerate(todo):
+                    cache.put(flat_ids[j], new[row])
+            feats = torch.stack([cache.get(fid) for fid in flat_ids], dim=0)
+        elif unbatched_matching_encoder_forward:
             feats = torch.cat([self.matching_model(f) for f in flat.split(1, dim=0)], dim=0)
         else:
             feats = self.matching_model(flat)
@@ -113,6 +170,6 @@ class DepthModelCVHint(nn.Module):
         cur_cam_T_src_cam = cur_data["cam_T_world_b44"].unsqueeze(1) @ src_data["world_T_cam_b44"]
         cur_feats = self.encoder(cur_data["image_b3hw"])
         m_cur, m_src = self.compute_matching_feats(cur_data["image_b3hw"], src_data["image_b3hw"],
-                                                   unbatched_matching_encoder_forward)
+                                                   unbatched_matching_encoder_forward)  # (ids: opt-in, see above)
         return self.forward_from_features(cur_feats, m_cur, m_src, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K,
                                           cur_invK, cur_data, return_mask=return_mask)

@@ -162,3 +162,38 @@ def test_replicate_padding_and_relu_conv():
     for impl in ("mfma", "simple"):
         got = ops.conv2d([(ops.as_nhwc(x.to(gu.dev())), False)], cd, act=ops.ACT_RELU, impl=impl)
         assert (got.cpu() - want).abs().max() < 2e-5, impl
+
+
+@pytest.mark.gpu
+def test_model_matching_feats_and_cross_frame_cache():
+    import gpu_util as gu
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
+
+    model = DepthModelCVHint(64, 96, depth_decoder_name="skip", matching_num_depth_bins=8, model_num_views=4)
+    _fill(model.matching_model, 21)
+    model = model.to(gu.dev())
+    b, k = 2, 3
+    cur = torch.from_numpy(syn.hash_normalish((b, 3, 64, 96), 31)).to(gu.dev())
+    src = torch.from_numpy(syn.hash_normalish((b, k, 3, 64, 96), 32)).to(gu.dev())
+    m_cur, m_src = model.compute_matching_feats(cur, src)
+    assert tuple(m_cur.shape) == (b, 16, 16, 24) and tuple(m_src.shape) == (b, k, 16, 16, 24)
+    u_cur, u_src = model.compute_matching_feats(cur, src, unbatched_matching_encoder_forward=True)
+    assert (u_cur - m_cur).abs().max() < 1e-4 and (u_src - m_src).abs().max() < 1e-4
+    # cached: ids laid out like src_data["frame_id_string"] (K lists of b strings)
+    cur_ids = ["f10", "f20"]
+    src_ids = [["f9", "f19"], ["f8", "f18"], ["f7", "f10"]]  # f10 is also a source of the second element
+    src2 = src.clone()
+    src2[1, 2] = cur[0]
+    c_cur, c_src = model.compute_matching_feats(cur, src2, cur_ids=cur_ids, src_ids=src_ids)
+    cache = model.matching_feature_cache
+    assert len(cache) == 7 and cache.misses == 7
+    ref_cur, ref_src = model.compute_matching_feats(cur, src2)
+    assert (c_cur - ref_cur).abs().max() < 1e-4 and (c_src - ref_src).abs().max() < 1e-4
+    assert torch.equal(c_src[1, 2], c_cur[0])
+    # next tuple: one new frame, everything else served from HBM
+    cur_b = torch.from_numpy(syn.hash_normalish((b, 3, 64, 96), 33)).to(gu.dev())
+    model.compute_matching_feats(cur_b, src2, cur_ids=["f11", "f21"], src_ids=src_ids)
+    assert cache.misses == 9 and len(cache) == 9
+    cache.capacity = 4
+    cache.put("x", c_cur[0])
+    assert len(cache) == 4 and "x" in cache
