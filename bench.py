@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the model part of the step from 3 hipGraphs (cut around the dominant kernel) instead of "
                          "launching eagerly; measured no faster -- the eager step is already GPU-bound (DESIGN.md 4.3)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still create the RCCL process group and run the per-step all_gather "
+                         "(checks the N>1 code path on a single GPU)")
     args = ap.parse_args()
 
     import torch
@@ -153,9 +156,13 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"  # the version banner goes to stdout, which carries the ONE JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from doubletake_amd import _abi
     from doubletake_amd.modules import cost_volume as cvmod
@@ -165,7 +172,8 @@ def main():
     inp, pyr, t, pyr_t = build_inputs(device, seed=1000 + rank)
     model = build_model(device)
     hint = {n: t[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
-    fuser = None if args.no_fuse else KeyframeShardFuser(device, world, rank, CFG["image_h"], CFG["image_w"])
+    fuser = None if args.no_fuse else KeyframeShardFuser(device, world, rank, CFG["image_h"], CFG["image_w"],
+                                                         force_collective=args.force_dist)
 
     events = []
 
@@ -231,7 +239,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
     if graphs is None:
@@ -240,13 +248,13 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i, timed=True)
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     cvmod.FeatureVolumeManager._event_hook = None
 
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -320,7 +328,7 @@ def main():
                           f"oracle/networks_ref.py), {sec:.1f} s; BLAS threads = cores, other numpy ops single-threaded",
             }
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -39,9 +39,10 @@ def shard_keyframes(num_frames: int, world: int, rank: int):
     return list(range(rank, num_frames, world))
 
 
-def exchange_updates(local: torch.Tensor, world: int) -> torch.Tensor:
-    """all_gather of the packed updates -> [world * b, n] in rank-major (canonical) order."""
-    if world == 1:
+def exchange_updates(local: torch.Tensor, world: int, force_collective: bool = False) -> torch.Tensor:
+    """all_gather of the packed updates -> [world * b, n] in rank-major (canonical) order.
+    force_collective: issue the collective even for world == 1 (single-GPU check of the RCCL path)."""
+    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         return local
     out = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())  # concatenation along dim 0 = rank-major order
@@ -55,10 +56,12 @@ class KeyframeShardFuser:
 
     BOUNDS = dict(xmin=-4.0, xmax=4.0, ymin=-4.0, ymax=4.0, zmin=0.0, zmax=3.2)
 
-    def __init__(self, device, world, rank, image_h, image_w, fuse_fn=None, pool=64, resolution=0.04, max_depth=3.0):
+    def __init__(self, device, world, rank, image_h, image_w, fuse_fn=None, pool=64, resolution=0.04, max_depth=3.0,
+                 force_collective=False):
         from .utils import synthetic as syn
 
         self.world, self.rank, self.device = world, rank, device
+        self.force_collective = force_collective
         self.h, self.w = image_h // 2, image_w // 2  # depth_pred_s0 resolution
         self.fuser = None
         if fuse_fn is None:
@@ -74,19 +77,33 @@ class KeyframeShardFuser:
         self.T_pool = torch.from_numpy(T).to(device)
         self.K_pool16 = self.K_pool.half()
         self.T_pool16 = self.T_pool.half()
+        self.KT_pool16 = torch.cat([self.K_pool16.reshape(pool, 16), self.T_pool16.reshape(pool, 16)], 1).contiguous()
         self.pool = pool
+        self._local = None
+        self._all = None
 
     def exchange_and_fuse(self, depth_b1hw: torch.Tensor, frame_idx: int):
         b = depth_b1hw.shape[0]
         gidx = [(frame_idx * self.world + self.rank) * b + i for i in range(b)]
-        if self.world == 1 and b == 1:
+        if self.world == 1 and b == 1 and not self.force_collective:
             # single GPU: nothing to exchange -- integrate the own frame directly (no packing kernels)
             j = gidx[0] % self.pool
             self.fuse_fn(depth_b1hw, self.K_pool16[j:j + 1], self.T_pool16[j:j + 1])
             return 1
-        sel = torch.tensor([g % self.pool for g in gidx], device=self.device)
-        local = pack_update(depth_b1hw, self.K_pool[sel], self.T_pool[sel])
-        allbuf = exchange_updates(local, self.world)
+        # pack into a preallocated fp16 buffer: one converting copy for the depth, one for [K | T]
+        n = self.h * self.w
+        if self._local is None or self._local.shape[0] != b:
+            self._local = torch.empty((b, n + 32), dtype=torch.float16, device=self.device)
+            self._all = torch.empty((self.world * b, n + 32), dtype=torch.float16, device=self.device)
+        self._local[:, :n].copy_(depth_b1hw.reshape(b, n))
+        for i, g in enumerate(gidx):
+            j = g % self.pool
+            self._local[i, n:].copy_(self.KT_pool16[j])
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            allbuf = self._local
+        else:
+            dist.all_gather_into_tensor(self._all, self._local)  # rank-major = canonical frame order
+            allbuf = self._all
         depth, K, T = unpack_update(allbuf, self.h, self.w)
         self.fuse_fn(depth, K, T)
         return depth.shape[0]
