@@ -158,8 +158,15 @@ def main():
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
+        # RCCL prints its NCCL_DEBUG=VERSION banner (exported by this image) on stdout, which carries the ONE
+        # JSON line: report the version on stderr instead
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"  # the version banner goes to stdout, which carries the ONE JSON line
+            del os.environ["NCCL_DEBUG"]
+            if rank == 0:
+                try:
+                    print(f"[bench] RCCL {'.'.join(map(str, torch.cuda.nccl.version()))}", file=sys.stderr)
+                except Exception:
+                    pass
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)

@@ -88,7 +88,11 @@ __device__ void matmul_half(const float* A, const float* B, float* C, int ra, in
 
 __global__ void tsdf_frame_setup_kernel(const uint16_t* __restrict__ K16, const uint16_t* __restrict__ T16, int img_h,
                                         int img_w, float depth_min, float depth_max, float* __restrict__ fp) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (threadIdx.x != 0) return;
+  // one workgroup per frame: frame f reads K16 + 16 f, T16 + 16 f and writes fp + kFrameParams f
+  K16 += (size_t)blockIdx.x * 16;
+  T16 += (size_t)blockIdx.x * 16;
+  fp += (size_t)blockIdx.x * kFrameParams;
   float K[16], T[16], invK[16], pose[16], P[16];
   for (int i = 0; i < 16; ++i) {
     K[i] = h2f(K16[i]);
@@ -139,7 +143,11 @@ struct TsdfConsts {
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restrict__ values, uint16_t* __restrict__ weights,
                                                             uint32_t* __restrict__ active, int X, int Y, int Z,
                                                             const uint16_t* __restrict__ depth, int img_h, int img_w,
-                                                            const float* __restrict__ fp, const TsdfConsts c) {
+                                                            const float* __restrict__ fp_all, int num_frames,
+                                                            const TsdfConsts c) {
+  // num_frames frames are integrated IN ORDER per voxel (the update is order dependent through the half
+  // running mean and the weight clamp, tools/tsdf.py:553-558); the voxel's value/weight stay in registers
+  // between frames, rounded to half exactly where the reference stores them.
   const size_t total = (size_t)X * Y * Z;
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool is_active = false;
@@ -151,8 +159,12 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
     const float cx = rh(c.origin[0] + (float)i * c.voxel_size);
     const float cy = rh(c.origin[1] + (float)j * c.voxel_size);
     const float cz = rh(c.origin[2] + (float)k * c.voxel_size);
-    const bool inside = cx > fp[12] && cx < fp[15] && cy > fp[13] && cy < fp[16] && cz > fp[14] && cz < fp[17];
-    if (inside) {
+    bool loaded = false, dirty = false;
+    float cur_v = 0.f, cur_w = 0.f;
+    for (int f = 0; f < num_frames; ++f) {
+      const float* fp = fp_all + (size_t)f * kFrameParams;
+      const bool inside = cx > fp[12] && cx < fp[15] && cy > fp[13] && cy < fp[16] && cz > fp[14] && cz < fp[17];
+      if (!inside) continue;
       float q[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
       const float xn = rintf(ix), yn = rintf(iy);
       float sd = 0.f;
       if (xn >= 0.f && xn < (float)img_w && yn >= 0.f && yn < (float)img_h)  // false for NaN/inf
-        sd = h2f(depth[(size_t)(int)yn * img_w + (int)xn]);
+        sd = h2f(depth[((size_t)f * img_h + (int)yn) * img_w + (int)xn]);
       const float vd = q[2];
       float t = rh(sd - c.min_depth);
       t = rh(t / c.depth_range);
@@ -183,14 +195,23 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
       const float tsdf = fminf(fmaxf(rh(dist / c.trunc), -1.0f), 1.0f);
       const bool valid = (vd > 0.f) && (dist > c.thr_neg) && (sd > 0.f) && (vd < c.max_depth_h) && (conf > 0.f);
       if (valid) {
-        is_active = dist < c.thr_pos;
-        const float old_v = h2f(values[id]), old_w = h2f(weights[id]);
+        is_active |= dist < c.thr_pos;
+        if (!loaded) {
+          cur_v = h2f(values[id]);
+          cur_w = h2f(weights[id]);
+          loaded = true;
+        }
         const float new_w = rh(rh(conf * 2.5f) / 100.0f);
-        const float tot = rh(old_w + new_w);
-        const float num = rh(rh(old_v * old_w) + rh(tsdf * new_w));
-        values[id] = f2h(num / tot);
-        weights[id] = f2h(fminf(tot, 1.0f));
+        const float tot = rh(cur_w + new_w);
+        const float num = rh(rh(cur_v * cur_w) + rh(tsdf * new_w));
+        cur_v = rh(num / tot);
+        cur_w = rh(fminf(tot, 1.0f));
+        dirty = true;
       }
+    }
+    if (dirty) {
+      values[id] = f2h(cur_v);
+      weights[id] = f2h(cur_w);
     }
   }
   // active bitmap: bit id of word id>>5.  A wave covers 64 consecutive ids = two whole words
@@ -251,20 +272,33 @@ extern "C" {
 
 int dt_tsdf_frame_params_floats(void) { return kFrameParams; }
 
+int dt_tsdf_frames_setup_f16(const uint16_t* K16, const uint16_t* T16, int num_frames, int img_h, int img_w,
+                             float depth_min, float depth_max, float* frame_params, dt_stream_t s) {
+  DT_REQUIRE(K16 && T16 && frame_params, "dt_tsdf_frames_setup_f16: null pointer");
+  DT_REQUIRE(img_h > 0 && img_w > 0 && num_frames > 0, "dt_tsdf_frames_setup_f16: bad extents");
+  hipLaunchKernelGGL(tsdf_frame_setup_kernel, dim3(num_frames), dim3(64), 0, to_stream(s), K16, T16, img_h, img_w, depth_min,
+                     depth_max, frame_params);
+  return check_launch("dt_tsdf_frames_setup_f16");
+}
+
 int dt_tsdf_frame_setup_f16(const uint16_t* K16, const uint16_t* T16, int img_h, int img_w, float depth_min,
                             float depth_max, float* frame_params, dt_stream_t s) {
-  DT_REQUIRE(K16 && T16 && frame_params, "dt_tsdf_frame_setup_f16: null pointer");
-  DT_REQUIRE(img_h > 0 && img_w > 0, "dt_tsdf_frame_setup_f16: bad image extent");
-  hipLaunchKernelGGL(tsdf_frame_setup_kernel, dim3(1), dim3(64), 0, to_stream(s), K16, T16, img_h, img_w, depth_min,
-                     depth_max, frame_params);
-  return check_launch("dt_tsdf_frame_setup_f16");
+  return dt_tsdf_frames_setup_f16(K16, T16, 1, img_h, img_w, depth_min, depth_max, frame_params, s);
 }
 
 int dt_tsdf_integrate_f16(uint16_t* values, uint16_t* weights, uint32_t* active, const float* origin3, float voxel_size,
                           int X, int Y, int Z, const uint16_t* depth, int img_h, int img_w, const float* frame_params,
                           const dt_tsdf_thresholds* th, dt_stream_t s) {
+  return dt_tsdf_integrate_frames_f16(values, weights, active, origin3, voxel_size, X, Y, Z, depth, 1, img_h, img_w,
+                                      frame_params, th, s);
+}
+
+int dt_tsdf_integrate_frames_f16(uint16_t* values, uint16_t* weights, uint32_t* active, const float* origin3,
+                                 float voxel_size, int X, int Y, int Z, const uint16_t* depth, int num_frames, int img_h,
+                                 int img_w, const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s) {
   DT_REQUIRE(values && weights && active && origin3 && depth && frame_params && th, "dt_tsdf_integrate_f16: null pointer");
-  DT_REQUIRE(X > 0 && Y > 0 && Z > 0 && img_h > 0 && img_w > 0 && voxel_size > 0.f, "dt_tsdf_integrate_f16: bad extents");
+  DT_REQUIRE(X > 0 && Y > 0 && Z > 0 && img_h > 0 && img_w > 0 && voxel_size > 0.f && num_frames > 0,
+             "dt_tsdf_integrate_f16: bad extents");
   const size_t total = (size_t)X * Y * Z;
   DT_REQUIRE(total % 32 == 0, "dt_tsdf_integrate_f16: voxel count must be a multiple of 32 (dims are multiples of 8)");
   TsdfConsts c;
@@ -284,7 +318,7 @@ int dt_tsdf_integrate_f16(uint16_t* values, uint16_t* weights, uint32_t* active,
   const size_t blocks = (total + 255) / 256;
   DT_REQUIRE(blocks < 2147483647ull, "dt_tsdf_integrate_f16: volume too large for one launch");
   hipLaunchKernelGGL(tsdf_integrate_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(s), values, weights, active, X,
-                     Y, Z, depth, img_h, img_w, frame_params, c);
+                     Y, Z, depth, img_h, img_w, frame_params, num_frames, c);
   return check_launch("dt_tsdf_integrate_f16");
 }
 

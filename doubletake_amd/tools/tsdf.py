@@ -231,7 +231,8 @@ class TSDFFuser:
         self.truncation_size = 3.0
         self.maxW = 100.0
         L = _abi.lib()
-        self._frame_params = torch.empty(L.dt_tsdf_frame_params_floats(), dtype=torch.float32, device=tsdf.device)
+        self._fp_floats = int(L.dt_tsdf_frame_params_floats())
+        self._frame_params = torch.empty(self._fp_floats, dtype=torch.float32, device=tsdf.device)
 
     voxel_size = property(lambda self: self.tsdf.voxel_size)
     tsdf_values = property(lambda self: self.tsdf.tsdf_values)
@@ -270,10 +271,14 @@ class TSDFFuser:
         depth_min = 0.01
         depth_max = self.max_depth + self.truncation + 0.1
         o = (C.c_float * 3)(*[float(v) for v in t.origin_f32])
-        for b in range(depth.shape[0]):
-            _abi.check(L.dt_tsdf_frame_setup_f16(_abi.ptr(K16[b]), _abi.ptr(T16[b]), img_h, img_w, float(np.float32(depth_min)),
-                                                 float(np.float32(depth_max)), _abi.ptr(self._frame_params), stream),
-                       "dt_tsdf_frame_setup_f16")
-            _abi.check(L.dt_tsdf_integrate_f16(_abi.ptr(t.tsdf_values), _abi.ptr(t.tsdf_weights), _abi.ptr(t.voxel_bitmap), o,
-                                               float(np.float32(t.voxel_size)), X, Y, Z, _abi.ptr(depth[b, 0]), img_h, img_w,
-                                               _abi.ptr(self._frame_params), C.byref(th), stream), "dt_tsdf_integrate_f16")
+        nf = depth.shape[0]
+        if self._frame_params.numel() < nf * self._fp_floats:
+            self._frame_params = torch.empty(nf * self._fp_floats, dtype=torch.float32, device=dev)
+        # all frames of the batch in two launches; the kernel applies them in batch order per voxel
+        _abi.check(L.dt_tsdf_frames_setup_f16(_abi.ptr(K16), _abi.ptr(T16), nf, img_h, img_w, float(np.float32(depth_min)),
+                                              float(np.float32(depth_max)), _abi.ptr(self._frame_params), stream),
+                   "dt_tsdf_frames_setup_f16")
+        _abi.check(L.dt_tsdf_integrate_frames_f16(_abi.ptr(t.tsdf_values), _abi.ptr(t.tsdf_weights), _abi.ptr(t.voxel_bitmap), o,
+                                                  float(np.float32(t.voxel_size)), X, Y, Z, _abi.ptr(depth), nf, img_h, img_w,
+                                                  _abi.ptr(self._frame_params), C.byref(th), stream),
+                   "dt_tsdf_integrate_frames_f16")

@@ -220,6 +220,19 @@ int dt_tsdf_integrate_f16(uint16_t* values, uint16_t* weights, uint32_t* active,
                           const float* origin3, float voxel_size, int X, int Y, int Z,
                           const uint16_t* depth_hw_f16, int img_h, int img_w,
                           const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s);
+/* Batched forms: num_frames frames in ONE launch each.  K16/T16: [num_frames,16] halves;
+ * frame_params: [num_frames, dt_tsdf_frame_params_floats()]; depth: [num_frames,img_h,img_w].
+ * Frames are applied in index order per voxel (the reference's batch loop, tools/tsdf.py:440-445),
+ * so the result is bit-identical to num_frames single-frame calls; the voxel is read and written
+ * once instead of once per frame. */
+int dt_tsdf_frames_setup_f16(const uint16_t* K16, const uint16_t* T16, int num_frames, int img_h,
+                             int img_w, float depth_min, float depth_max, float* frame_params,
+                             dt_stream_t s);
+int dt_tsdf_integrate_frames_f16(uint16_t* values, uint16_t* weights, uint32_t* active,
+                                 const float* origin3, float voxel_size, int X, int Y, int Z,
+                                 const uint16_t* depth_f16, int num_frames, int img_h, int img_w,
+                                 const float* frame_params, const dt_tsdf_thresholds* th,
+                                 dt_stream_t s);
 /* replaces: TSDF.sample_tsdf (tools/tsdf.py:277-339), trilinear, align_corners=True, zeros
  * padding.  fp16_math = 0 reproduces the reference's CPU branch (fp32 math on the half volume,
  * pinned by goldens); 1 rounds grid and result to half like its GPU branch (unpinned).

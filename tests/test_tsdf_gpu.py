@@ -152,3 +152,24 @@ def test_full_size_volume_one_frame_vs_oracle():
     np.testing.assert_array_equal(t.active_keys().cpu().numpy().astype(np.int64),
                                   np.array(sorted(vol.active), dtype=np.int64).reshape(-1, 3))
     assert len(vol.active) > 10000
+
+
+def test_batched_integrate_equals_frame_by_frame():
+    """One launch over 5 frames (ordered per voxel, value kept in registers) == 5 single-frame launches, bit for bit."""
+    import gpu_util as gu
+    from doubletake_amd.tools.fusers_helper import OurFuser
+
+    vs, maxd, ext, H, W, seed = RUNS["a"]
+    depth, K, T = syn.tsdf_frames(5, H, W, seed=seed, bounds=BD)
+    depth = depth * np.float32(0.6)
+    d, k, t = (torch.from_numpy(a).to(gu.dev()) for a in (depth, K, T))
+    one = OurFuser(None, vs, maxd, bounds=BD)
+    for f in range(5):
+        one.fuse_frames(d[f:f + 1], k[f:f + 1], t[f:f + 1], None)
+    allf = OurFuser(None, vs, maxd, bounds=BD)
+    allf.fuse_frames(d, k, t, None)
+    a, b = one.tsdf_fuser_pred.tsdf, allf.tsdf_fuser_pred.tsdf
+    assert torch.equal(a.tsdf_values.view(torch.int16), b.tsdf_values.view(torch.int16))
+    assert torch.equal(a.tsdf_weights.view(torch.int16), b.tsdf_weights.view(torch.int16))
+    assert torch.equal(a.voxel_bitmap, b.voxel_bitmap)
+    assert (b.tsdf_weights > 0).sum().item() > 1000
