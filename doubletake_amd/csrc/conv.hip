@@ -59,10 +59,12 @@ __device__ __forceinline__ int pixel_offset(bool inside, int n, int iy, int ix, 
 //   1  : every wave owns a whole block (4 blocks per 256-thread workgroup), no reduction;
 //        used when the layer has enough blocks to fill the chip on its own
 //   4  : one block per 256-thread workgroup, 4-way K split, LDS reduction
-//   8  : one block per 512-thread workgroup, 8-way K split (the 15x20 / 30x40 levels)
+//   8  : one block per 512-thread workgroup, 8-way K split (the 30x40 level)
+//   16 : one block per 1024-thread workgroup, 16-way K split (only the low-resolution 1x1 downsample convs:
+//        for the 3x3 layers of the 15x20 level it measured 10 % slower than 8)
 template <int KS, int ST, int SPLIT>
-__global__ __launch_bounds__(SPLIT == 8 ? 512 : 256) void conv_mfma_kernel(const ConvArgs a) {
-  constexpr int NW = (SPLIT == 8) ? 8 : 4;
+__global__ __launch_bounds__(SPLIT >= 8 ? SPLIT * 64 : 256) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int NW = (SPLIT >= 8) ? SPLIT : 4;
   constexpr int IH = (kPH - 1) * ST + KS, IW = (kPW - 1) * ST + KS;
   constexpr int NPIX = IH * IW;
   constexpr int NLOAD = (NPIX + 31) / 32;  // float4 staging loads per lane and group
@@ -520,7 +522,7 @@ __global__ void conv_simple_kernel(const ConvArgs a, const float* __restrict__ W
 // ---- 1x1 conv to one channel: one wave per 64 pixels, lanes own pixels -----------------------
 __global__ __launch_bounds__(256) void conv1x1_head_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                          int64_t pixels, int c) {
+                                                          float* __restrict__ out_exp, int64_t pixels, int c) {
   // 4 lanes cooperate on one pixel (float4 strided over channels), shuffle-reduce
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t pix = t >> 2;
@@ -536,7 +538,11 @@ __global__ __launch_bounds__(256) void conv1x1_head_kernel(const float* __restri
   }
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
-  if (pix < pixels && sub == 0) out[pix] = acc + (bias ? bias[0] : 0.f);
+  if (pix < pixels && sub == 0) {
+    const float v = acc + (bias ? bias[0] : 0.f);
+    out[pix] = v;
+    if (out_exp) out_exp[pix] = expf(v);
+  }
 }
 
 // ---- bilinear x2 upsample (align_corners=False), NHWC, float4 over channels ------------------
@@ -620,6 +626,13 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
   return 0;
 }
 
+// the 16-way split only exists for stride 1 (a stride-2 patch per wave would need 78 KB of LDS)
+template <int KS, int ST>
+static void launch_split16(const ConvArgs& a, long blocks, hipStream_t st) {
+  if constexpr (ST == 1)
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, ST, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
+}
+
 }  // namespace dt
 
 using namespace dt;
@@ -672,7 +685,14 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
   else {
     const long pix_blocks = ((long)a.n * a.h_out * a.w_out + 31) / 32;
     const long waves = pix_blocks * a.co_blocks;
-    hipLaunchKernelGGL(conv1x1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    // few pixels, long K (the low-resolution downsample convs): one wave per block leaves most SIMDs idle
+    // and runs hundreds of dependent MFMAs in a row -> K-split variant of the tiled kernel instead
+    if (waves < 1024 && a.groups >= 32 && blocks * 8 < 2048)
+      launch_split16<1, 1>(a, blocks, st);
+    else if (waves < 1024 && a.groups >= 16)
+      hipLaunchKernelGGL((conv_mfma_kernel<1, 1, 8>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+    else
+      hipLaunchKernelGGL(conv1x1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
   }
 #undef DT_LAUNCH_CONV
   return check_launch("dt_conv2d_f32");
@@ -690,13 +710,13 @@ int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in0, const float* i
   return check_launch("dt_conv2d_simple_f32");
 }
 
-int dt_conv1x1_head_f32(const float* in, const float* w, const float* bias, float* out, int64_t pixels, int c,
-                        dt_stream_t s) {
+int dt_conv1x1_head_f32(const float* in, const float* w, const float* bias, float* out, float* out_exp, int64_t pixels,
+                        int c, dt_stream_t s) {
   DT_REQUIRE(in && w && out, "dt_conv1x1_head_f32: null pointer");
   DT_REQUIRE(pixels > 0 && c > 0 && c % 4 == 0, "dt_conv1x1_head_f32: bad extents pixels=%ld c=%d", (long)pixels, c);
   const int64_t threads = pixels * 4;
   hipLaunchKernelGGL(conv1x1_head_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, to_stream(s), in, w, bias,
-                     out, pixels, c);
+                     out, out_exp, pixels, c);
   return check_launch("dt_conv1x1_head_f32");
 }
 

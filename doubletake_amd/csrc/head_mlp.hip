@@ -22,6 +22,7 @@ struct HeadArgs {
   const float* wb;    // packed [64 steps][256]
   const float* tail;  // kHeadTail
   float* out;         // [pixels]
+  float* out_exp;     // optional [pixels]: expf(out) (the depth of a log-depth head)
   long pixels;
   int cin;
 };
@@ -128,7 +129,11 @@ __global__ __launch_bounds__(256, 1) void head_mlp_kernel(const HeadArgs a) {
     }
     s += __shfl_xor(s, 32, 64);
     const long pix = t * 32 + p;
-    if (half == 0 && pix < a.pixels) a.out[pix] = s + bc;
+    if (half == 0 && pix < a.pixels) {
+      const float v = s + bc;
+      a.out[pix] = v;
+      if (a.out_exp) a.out_exp[pix] = expf(v);
+    }
   }
 }
 
@@ -148,8 +153,8 @@ int dt_head_mlp_pack_floats(int cin, int* wa, int* wb, int* tail) {
   return 0;
 }
 
-int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, const float* tail, float* out, int64_t pixels,
-                    int cin, dt_stream_t s) {
+int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, const float* tail, float* out, float* out_exp,
+                    int64_t pixels, int cin, dt_stream_t s) {
   DT_REQUIRE(in_nhwc && wa && wb && tail && out, "dt_head_mlp_f32: null pointer");
   DT_REQUIRE(pixels > 0, "dt_head_mlp_f32: pixels=%ld", (long)pixels);
   DT_REQUIRE(cin == 64 || cin == 128, "dt_head_mlp_f32: cin=%d (64 or 128 supported)", cin);
@@ -162,7 +167,7 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
     g_head_cus = n;
   }
   HeadArgs a;
-  a.in = in_nhwc; a.wa = wa; a.wb = wb; a.tail = tail; a.out = out; a.pixels = pixels; a.cin = cin;
+  a.in = in_nhwc; a.wa = wa; a.wb = wb; a.tail = tail; a.out = out; a.out_exp = out_exp; a.pixels = pixels; a.cin = cin;
   const long tiles = (pixels + 31) / 32;
   const long want = (tiles + 3) / 4;
   const int blocks = (int)(want < g_head_cus ? want : g_head_cus);

@@ -147,13 +147,17 @@ class DepthModelCVHint(nn.Module):
             return_mask=return_mask, cv_depth_hint_dict=cv_depth_hint_dict)
         cv_feats = self.cost_volume_net(cost_volume, cur_feats[self.matching_scale:])
         feats = list(cur_feats[: self.matching_scale]) + cv_feats
-        depth_outputs = self.depth_decoder(feats)
+        if isinstance(self.depth_decoder, SkipDecoderRegression):
+            depth_outputs = self.depth_decoder(feats, with_depth=True)  # heads write exp(log depth) themselves
+        else:
+            depth_outputs = self.depth_decoder(feats)
         for k in list(depth_outputs.keys()):
             if not k.startswith("log_depth"):
                 continue
             log_depth = depth_outputs[k].float()
             depth_outputs[k] = log_depth
-            depth_outputs[k.replace("log_", "")] = ops.exp(log_depth)
+            if k.replace("log_", "") not in depth_outputs:
+                depth_outputs[k.replace("log_", "")] = ops.exp(log_depth)
         depth_outputs["lowest_cost_bhw"] = lowest_cost
         depth_outputs["overall_mask_bhw"] = overall_mask
         return depth_outputs

@@ -136,8 +136,9 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
     return out
 
 
-def conv1x1_head(x, conv: nn.Conv2d):
-    """1x1 conv to a single channel (regression head): NHWC [n,c,h,w] -> [n,1,h,w]."""
+def conv1x1_head(x, conv: nn.Conv2d, with_exp=False):
+    """1x1 conv to a single channel (regression head): NHWC [n,c,h,w] -> [n,1,h,w].
+    with_exp: return (out, exp(out)) from the same launch."""
     if conv.kernel_size != (1, 1) or conv.out_channels != 1:
         raise NotImplementedError("head must be a 1x1 conv to one channel")
     L = _abi.lib()
@@ -146,14 +147,15 @@ def conv1x1_head(x, conv: nn.Conv2d):
     out = torch.empty((n, 1, h, w), device=dev, dtype=torch.float32)
     wv = _dev_param(conv, "weight", dev)
     b = _dev_param(conv, "bias", dev)
-    _abi.check(L.dt_conv1x1_head_f32(_abi.ptr(x), _abi.ptr(wv), _abi.ptr(b), _abi.ptr(out), n * h * w, c,
+    out_e = torch.empty_like(out) if with_exp else None
+    _abi.check(L.dt_conv1x1_head_f32(_abi.ptr(x), _abi.ptr(wv), _abi.ptr(b), _abi.ptr(out), _abi.ptr(out_e), n * h * w, c,
                                      _abi.current_stream(dev)), "dt_conv1x1_head_f32")
-    return out
+    return (out, out_e) if with_exp else out
 
 
-def head_mlp(x, head: nn.Sequential):
+def head_mlp(x, head: nn.Sequential, with_exp=False):
     """Fused 1x1 -> ELU -> 1x1 -> ELU -> 1x1 regression head (modules/networks_fast.py:102-132).
-    x NHWC [n,c,h,w] (c = 64 or 128) -> [n,1,h,w]."""
+    x NHWC [n,c,h,w] (c = 64 or 128) -> [n,1,h,w]; with_exp: (out, exp(out)) from the same launch."""
     from . import mlp_pack
 
     L = _abi.lib()
@@ -170,9 +172,10 @@ def head_mlp(x, head: nn.Sequential):
         head.__dict__["_dt_head_pack"] = hit
     pk = hit[1]
     out = torch.empty((n, 1, h, w), device=dev, dtype=torch.float32)
+    out_e = torch.empty_like(out) if with_exp else None
     _abi.check(L.dt_head_mlp_f32(_abi.ptr(x), _abi.ptr(pk["wa"]), _abi.ptr(pk["wb"]), _abi.ptr(pk["tail"]), _abi.ptr(out),
-                                 n * h * w, c, _abi.current_stream(dev)), "dt_head_mlp_f32")
-    return out
+                                 _abi.ptr(out_e), n * h * w, c, _abi.current_stream(dev)), "dt_head_mlp_f32")
+    return (out, out_e) if with_exp else out
 
 
 def head_mlp_supported(x, head) -> bool:

@@ -79,16 +79,23 @@ class SkipDecoderRegression(SkipDecoder):
                 nn.Conv2d(128, 1, kernel_size=1)))
 
     @torch.no_grad()
-    def forward(self, features, _impl="mfma"):
+    def forward(self, features, _impl="mfma", with_depth=False):
+        """Reference contract: {log_depth_pred_s{i}_b1hw, ...}.  with_depth (extension used by
+        DepthModelCVHint): the head kernels also write depth_pred_s{i}_b1hw = exp(log depth), saving the four
+        exp passes of experiment_modules/doubletake_model.py:410-418."""
         out = self._features(features, impl=_impl)
         for oi, scale in ((1, 3), (2, 2), (3, 1), (4, 0)):
             head = getattr(self, f"out{oi}")
             feat = out[f"feature_s{scale}_b1hw"]
             if _impl == "mfma" and ops.head_mlp_supported(feat, head):
                 # 64- and 128-channel heads (scales 0-2, 99 % of the pixels): one fused kernel
-                out[f"log_depth_pred_s{scale}_b1hw"] = ops.head_mlp(feat, head)
-                continue
-            y = ops.conv2d([(feat, False)], head[0], act=ops.ACT_ELU, impl=_impl)
-            y = ops.conv2d([(y, False)], head[2], act=ops.ACT_ELU, impl=_impl)
-            out[f"log_depth_pred_s{scale}_b1hw"] = ops.conv1x1_head(y, head[4])
+                res = ops.head_mlp(feat, head, with_exp=with_depth)
+            else:
+                y = ops.conv2d([(feat, False)], head[0], act=ops.ACT_ELU, impl=_impl)
+                y = ops.conv2d([(y, False)], head[2], act=ops.ACT_ELU, impl=_impl)
+                res = ops.conv1x1_head(y, head[4], with_exp=with_depth)
+            if with_depth:
+                out[f"log_depth_pred_s{scale}_b1hw"], out[f"depth_pred_s{scale}_b1hw"] = res
+            else:
+                out[f"log_depth_pred_s{scale}_b1hw"] = res
         return out

@@ -145,16 +145,18 @@ int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in0, const float* i
                          const float* in2, const float* W_oihw, const float* bias,
                          const float* residual, float* out, dt_stream_t s);
 /* 1x1 conv to ONE output channel (regression heads: modules/networks.py:60-63,
- * modules/networks_fast.py:102-132 last layer).  in NHWC [n,h,w,c] -> out [n,h,w]. */
+ * modules/networks_fast.py:102-132 last layer).  in NHWC [n,h,w,c] -> out [n,h,w].
+ * out_exp (may be NULL): also receives expf(out), the depth of a log-depth head
+ * (experiment_modules/doubletake_model.py:410-418) without a second pass. */
 int dt_conv1x1_head_f32(const float* in_nhwc, const float* w_c, const float* bias1,
-                        float* out, int64_t pixels, int c, dt_stream_t s);
+                        float* out, float* out_exp, int64_t pixels, int c, dt_stream_t s);
 /* Fused regression head of the small decoder: per pixel Cin -> 128 (ELU) -> 128 (ELU) -> 1, i.e. the
  * three 1x1 convs of SkipDecoderRegression.out{1..4} (modules/networks_fast.py:102-132,134-141) in
  * one kernel.  cin = 64 or 128; wa/wb/tail packed by doubletake_amd.modules.mlp_pack.pack_head_mlp
  * (sizes from dt_head_mlp_pack_floats).  in NHWC [pixels][cin] -> out [pixels]. */
 int dt_head_mlp_pack_floats(int cin, int* wa, int* wb, int* tail);
 int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, const float* tail,
-                    float* out, int64_t pixels, int cin, dt_stream_t s);
+                    float* out, float* out_exp, int64_t pixels, int cin, dt_stream_t s);
 /* bilinear x2 upsample, align_corners=False (utils/generic_utils.py:95-104), NHWC. */
 int dt_upsample2x_bilinear_f32(const float* in_nhwc, float* out_nhwc, int n, int h, int w,
                                int c, dt_stream_t s);
