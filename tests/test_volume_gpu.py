@@ -158,6 +158,8 @@ def test_linearity_in_last_layer_at_full_size():
 @pytest.mark.parametrize("name,b,k,h,w,D", [
     ("cfg3_batch8", 8, 7, 96, 128, 64),          # BASELINE configs[2]: ScanNet default 512x384, batch 8
     ("cfg5_portrait_D96", 2, 7, 128, 96, 96),    # BASELINE configs[4]: 3RScan rotated (portrait), 96 planes
+    ("tiny_one_view_D5", 3, 1, 3, 5, 5),         # fewer pixels than one MFMA tile, one source view, D % 8 != 0
+    ("ragged_D13", 1, 4, 7, 45, 13),             # partial tiles + partial store chunks
 ])
 def test_other_baseline_configs_mfma_vs_simple_and_oracle_probes(name, b, k, h, w, D):
     """Larger BASELINE shapes: the fused MFMA kernel against the independent one-thread-per-pair GPU
