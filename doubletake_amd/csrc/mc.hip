@@ -107,35 +107,44 @@ __global__ __launch_bounds__(256) void mc_count_kernel(const McArgs a, int* __re
   }
 }
 
-// exclusive scan of block_sums in place (single block, 1024 threads, chunked) + totals
+// exclusive scan of block_sums in place (single block, 1024 threads, chunked) + totals.
+// Per-thread chunk sums are scanned with wave shuffles, the 16 wave totals through LDS.
 __global__ __launch_bounds__(1024) void mc_scan_kernel(int* __restrict__ block_sums, const int* __restrict__ block_cells,
                                                       int nblocks, int* __restrict__ counts_out) {
-  __shared__ long long part[1024];
-  __shared__ long long cpart[1024];
-  const int t = threadIdx.x;
+  __shared__ long long wtot[16];
+  __shared__ long long ctot[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int per = (nblocks + 1023) / 1024;
-  const int b0 = t * per, b1 = min(b0 + per, nblocks);
+  const int b0 = min(t * per, nblocks), b1 = min(b0 + per, nblocks);
   long long s = 0, c = 0;
   for (int b = b0; b < b1; ++b) {
     s += block_sums[b];
     c += block_cells[b];
   }
-  part[t] = s;
-  cpart[t] = c;
-  __syncthreads();
-  if (t == 0) {
-    long long run = 0, crun = 0;
-    for (int q = 0; q < 1024; ++q) {
-      const long long v = part[q];
-      part[q] = run;
-      run += v;
-      crun += cpart[q];
-    }
-    counts_out[0] = (int)crun;
-    counts_out[1] = (run > 2147483647LL) ? -1 : (int)run;
+  long long incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const long long up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
   }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+  if (lane == 63) wtot[wave] = incl;
+  if (lane == 0) ctot[wave] = c;
   __syncthreads();
-  long long run = part[t];
+  long long base = 0, total = 0, cells = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const long long v = wtot[w];
+    if (w < wave) base += v;
+    total += v;
+    cells += ctot[w];
+  }
+  if (t == 0) {
+    counts_out[0] = (int)cells;
+    counts_out[1] = (total > 2147483647LL) ? -1 : (int)total;
+  }
+  long long run = base + incl - s;
   for (int b = b0; b < b1; ++b) {
     const int v = block_sums[b];
     block_sums[b] = (int)run;

@@ -22,20 +22,17 @@ __global__ void raster_init_kernel(uint32_t* __restrict__ zb, int64_t n) {
   if (i < n) zb[i] = 0xFFFFFFFFu;
 }
 
-__global__ void raster_faces_kernel(const float* __restrict__ verts, const int64_t* __restrict__ faces, int64_t num_faces,
-                                    const float* __restrict__ cam_T_world, const float* __restrict__ K, int h, int w,
-                                    uint32_t* __restrict__ zb) {
-  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= num_faces) return;
+// rasterise one triangle given in world coordinates
+__device__ __forceinline__ void raster_triangle(const float (&X)[3], const float (&Y)[3], const float (&Z)[3],
+                                                const float* __restrict__ cam_T_world, const float* __restrict__ K, int h,
+                                                int w, uint32_t* __restrict__ zb) {
   const float fx = K[0], cx = K[2], fy = K[5], cy = K[6];
   float sx[3], sy[3], sz[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int64_t vi = faces[f * 3 + i];
-    const float X = verts[vi * 3 + 0], Y = verts[vi * 3 + 1], Z = verts[vi * 3 + 2];
-    const float xc = cam_T_world[0] * X + cam_T_world[1] * Y + cam_T_world[2] * Z + cam_T_world[3];
-    const float yc = cam_T_world[4] * X + cam_T_world[5] * Y + cam_T_world[6] * Z + cam_T_world[7];
-    const float zc = cam_T_world[8] * X + cam_T_world[9] * Y + cam_T_world[10] * Z + cam_T_world[11];
+    const float xc = cam_T_world[0] * X[i] + cam_T_world[1] * Y[i] + cam_T_world[2] * Z[i] + cam_T_world[3];
+    const float yc = cam_T_world[4] * X[i] + cam_T_world[5] * Y[i] + cam_T_world[6] * Z[i] + cam_T_world[7];
+    const float zc = cam_T_world[8] * X[i] + cam_T_world[9] * Y[i] + cam_T_world[10] * Z[i] + cam_T_world[11];
     if (!(zc > 1e-2f)) return;
     sx[i] = fx * xc / zc + cx;
     sy[i] = fy * yc / zc + cy;
@@ -62,6 +59,41 @@ __global__ void raster_faces_kernel(const float* __restrict__ verts, const int64
       if (z > 0.f) atomicMin(zb + (size_t)y * w + x, __float_as_uint(z));
     }
   }
+}
+
+__global__ void raster_faces_kernel(const float* __restrict__ verts, const int64_t* __restrict__ faces, int64_t num_faces,
+                                    const float* __restrict__ cam_T_world, const float* __restrict__ K, int h, int w,
+                                    uint32_t* __restrict__ zb) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= num_faces) return;
+  float X[3], Y[3], Z[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int64_t vi = faces[f * 3 + i];
+    X[i] = verts[vi * 3 + 0];
+    Y[i] = verts[vi * 3 + 1];
+    Z[i] = verts[vi * 3 + 2];
+  }
+  raster_triangle(X, Y, Z, cam_T_world, K, h, w, zb);
+}
+
+// triangle soup straight from dt_mc_generate: vertex 3f+i of face f, in (k,j,i) voxel-index coordinates;
+// world = origin + (i,j,k) * voxel_size (what TSDF.to_mesh_pytorch3d(scale_to_world=True) computes after the
+// axis flip of utils/pytorch3d_extras.py:105).  Skips the sort/unique vertex merge, which rendering ignores.
+__global__ void raster_soup_kernel(const float* __restrict__ verts_kji, int64_t num_faces, float ox, float oy, float oz,
+                                   float vs, const float* __restrict__ cam_T_world, const float* __restrict__ K, int h, int w,
+                                   uint32_t* __restrict__ zb) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= num_faces) return;
+  float X[3], Y[3], Z[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float* v = verts_kji + (f * 3 + i) * 3;
+    X[i] = ox + v[2] * vs;
+    Y[i] = oy + v[1] * vs;
+    Z[i] = oz + v[0] * vs;
+  }
+  raster_triangle(X, Y, Z, cam_T_world, K, h, w, zb);
 }
 
 __global__ void raster_resolve_kernel(const uint32_t* __restrict__ zb, float* __restrict__ out, int64_t n) {
@@ -91,6 +123,22 @@ int dt_raster_depth_f32(const float* verts_v3, const int64_t* faces_f3, int64_t 
                        num_faces, cam_T_world_44, K_44, h, w, workspace_hw);
   hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, depth_hw, n);
   return check_launch("dt_raster_depth_f32");
+}
+
+int dt_raster_soup_depth_f32(const float* verts_kji_v3, int64_t num_faces, const float* origin3, float voxel_size,
+                             const float* cam_T_world_44, const float* K_44, int h, int w, uint32_t* workspace_hw,
+                             float* depth_hw, dt_stream_t s) {
+  DT_REQUIRE(cam_T_world_44 && K_44 && workspace_hw && depth_hw && origin3, "dt_raster_soup_depth_f32: null pointer");
+  DT_REQUIRE(h > 0 && w > 0 && num_faces >= 0 && voxel_size > 0.f, "dt_raster_soup_depth_f32: bad extents");
+  DT_REQUIRE(num_faces == 0 || verts_kji_v3, "dt_raster_soup_depth_f32: null mesh");
+  const int64_t n = (int64_t)h * w;
+  hipStream_t st = to_stream(s);
+  hipLaunchKernelGGL(raster_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, n);
+  if (num_faces > 0)
+    hipLaunchKernelGGL(raster_soup_kernel, dim3((unsigned)((num_faces + 127) / 128)), dim3(128), 0, st, verts_kji_v3, num_faces,
+                       origin3[0], origin3[1], origin3[2], voxel_size, cam_T_world_44, K_44, h, w, workspace_hw);
+  hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, depth_hw, n);
+  return check_launch("dt_raster_soup_depth_f32");
 }
 
 }  // extern "C"

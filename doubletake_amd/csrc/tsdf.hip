@@ -225,18 +225,17 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
   }
 }
 
-__global__ void tsdf_sample_kernel(const uint16_t* __restrict__ vol, float ox, float oy, float oz, float vs, int X, int Y,
-                                   int Z, const float* __restrict__ pts, float* __restrict__ out, int64_t n,
-                                   int fp16_math) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
+// trilinear sample (align_corners=True) of a half volume at one world point (tools/tsdf.py:277-339)
+__device__ __forceinline__ float sample_trilinear(const uint16_t* __restrict__ vol, float ox, float oy, float oz, float vs,
+                                                  int X, int Y, int Z, float wx_, float wy_, float wz_, int fp16_math) {
   const float dims[3] = {(float)X, (float)Y, (float)Z};
   const float org[3] = {ox, oy, oz};
+  const float pt[3] = {wx_, wy_, wz_};
   float idx[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     // world -> [-1,1] (tools/tsdf.py:306-319), then align_corners=True unnormalise
-    float vc = pts[t * 3 + a] - org[a];
+    float vc = pt[a] - org[a];
     vc = vc / vs;
     vc = vc / (dims[a] - 1.0f);
     vc = vc * 2.0f - 1.0f;
@@ -261,7 +260,45 @@ __global__ void tsdf_sample_kernel(const uint16_t* __restrict__ vol, float ox, f
           acc += h2f(vol[((size_t)xi * Y + yi) * Z + zi]) * (wx * wy * wz);
         }
   }
-  out[t] = fp16_math ? rh(acc) : acc;
+  return fp16_math ? rh(acc) : acc;
+}
+
+__global__ void tsdf_sample_kernel(const uint16_t* __restrict__ vol, float ox, float oy, float oz, float vs, int X, int Y,
+                                   int Z, const float* __restrict__ pts, float* __restrict__ out, int64_t n,
+                                   int fp16_math) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  out[t] = sample_trilinear(vol, ox, oy, oz, vs, X, Y, Z, pts[t * 3 + 0], pts[t * 3 + 1], pts[t * 3 + 2], fp16_math);
+}
+
+// Hint maps from a rendered depth (reference test_incremental.py:204-258 in one pass): back-project the
+// pixel centre (x+0.5, y+0.5) with invK and the camera pose, sample the fused WEIGHT volume there, and keep
+// the depth as a hint where a surface was rendered (depth != -1) and the sampled weight reaches `thr`.
+__global__ __launch_bounds__(256) void hint_from_depth_kernel(const float* __restrict__ depth, const uint16_t* __restrict__ wvol,
+                                                             float ox, float oy, float oz, float vs, int X, int Y, int Z,
+                                                             const float* __restrict__ invK, const float* __restrict__ pose,
+                                                             float thr, int h, int w, float* __restrict__ hint,
+                                                             float* __restrict__ mask_f, uint8_t* __restrict__ mask_b,
+                                                             float* __restrict__ weights) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h * w) return;
+  const int y = i / w, x = i - y * w;
+  const float d = depth[i];
+  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+  // (invK @ pix) * depth, then world_T_cam @ (cam, 1): same association as the reference's matmuls
+  // invK / pose: row-major 4x4
+  const float cx = (invK[0] * px + invK[1] * py + invK[2]) * d;
+  const float cy = (invK[4] * px + invK[5] * py + invK[6]) * d;
+  const float cz = (invK[8] * px + invK[9] * py + invK[10]) * d;
+  const float wx = pose[0] * cx + pose[1] * cy + pose[2] * cz + pose[3];
+  const float wy = pose[4] * cx + pose[5] * cy + pose[6] * cz + pose[7];
+  const float wz = pose[8] * cx + pose[9] * cy + pose[10] * cz + pose[11];
+  const float sw = sample_trilinear(wvol, ox, oy, oz, vs, X, Y, Z, wx, wy, wz, 0);
+  const bool keep = (d != -1.0f) && !(sw < thr) && (d == d);
+  hint[i] = keep ? d : __builtin_nanf("");
+  mask_f[i] = keep ? 1.0f : 0.0f;
+  mask_b[i] = keep ? 1 : 0;
+  weights[i] = keep ? sw : 0.0f;
 }
 
 }  // namespace dt
@@ -330,6 +367,20 @@ int dt_tsdf_sample_f16(const uint16_t* volume, const float* origin3, float voxel
   hipLaunchKernelGGL(tsdf_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, to_stream(s), volume, origin3[0],
                      origin3[1], origin3[2], voxel_size, X, Y, Z, points_n3, out_n, n, fp16_math);
   return check_launch("dt_tsdf_sample_f16");
+}
+
+int dt_hint_from_depth_f32(const float* depth_hw, const uint16_t* weights_vol_f16, const float* origin3, float voxel_size,
+                           int X, int Y, int Z, const float* invK_44, const float* world_T_cam_44, float threshold,
+                           int h, int w, float* hint_hw, float* mask_hw, uint8_t* mask_b_hw, float* sampled_weights_hw,
+                           dt_stream_t s) {
+  DT_REQUIRE(depth_hw && weights_vol_f16 && origin3 && invK_44 && world_T_cam_44 && hint_hw && mask_hw &&
+                 mask_b_hw && sampled_weights_hw,
+             "dt_hint_from_depth_f32: null pointer");
+  DT_REQUIRE(X > 1 && Y > 1 && Z > 1 && h > 0 && w > 0 && voxel_size > 0.f, "dt_hint_from_depth_f32: bad extents");
+  hipLaunchKernelGGL(hint_from_depth_kernel, dim3((unsigned)((h * w + 255) / 256)), dim3(256), 0, to_stream(s), depth_hw,
+                     weights_vol_f16, origin3[0], origin3[1], origin3[2], voxel_size, X, Y, Z, invK_44, world_T_cam_44, threshold, h, w, hint_hw,
+                     mask_hw, mask_b_hw, sampled_weights_hw);
+  return check_launch("dt_hint_from_depth_f32");
 }
 
 }  // extern "C"

@@ -81,6 +81,47 @@ def prepare_mesh_hint(fuser, mesh_renderer, cur_data, render_height, render_widt
     return depth
 
 
+@torch.no_grad()
+def prepare_mesh_hint_fused(fuser, cur_data, render_height, render_width, weight_threshold=0.025):
+    """Same outputs as prepare_mesh_hint in four kernels and no intermediate mesh object: marching-cubes
+    triangle soup -> depth render -> back-projection + weight sampling + threshold.  The rendered image can
+    differ from prepare_mesh_hint's in isolated pixels (vertices are not merged by edge id, so a shared vertex
+    may come from either neighbouring cell's interpolation: <= 1 ulp apart)."""
+    import ctypes as C
+
+    from .pytorch3d_extras import marching_cubes_raw
+
+    L = _abi.lib()
+    tsdf = fuser.tsdf_fuser_pred.tsdf
+    dev = tsdf.device
+    stream = _abi.current_stream(dev)
+    verts, _, _ = marching_cubes_raw(tsdf.tsdf_values, tsdf.voxel_bitmap, 0.0)
+    nf = int(verts.shape[0]) // 3
+    h, w = render_height, render_width
+    o = (C.c_float * 3)(*[float(v) for v in tsdf.origin.float().tolist()])
+    T = cur_data["cam_T_world_b44"][0].to(device=dev, dtype=torch.float32).contiguous()
+    K = cur_data["K_s0_b44"][0].to(device=dev, dtype=torch.float32).contiguous()
+    depth = torch.empty(1, 1, h, w, device=dev, dtype=torch.float32)
+    ws = torch.empty(h * w, device=dev, dtype=torch.int32)
+    _abi.check(L.dt_raster_soup_depth_f32(_abi.ptr(verts), nf, o, float(tsdf.voxel_size), _abi.ptr(T), _abi.ptr(K), h, w,
+                                          _abi.ptr(ws), _abi.ptr(depth), stream), "dt_raster_soup_depth_f32")
+    invK = cur_data["invK_s0_b44"][0].to(device=dev, dtype=torch.float32).contiguous()
+    pose = cur_data["world_T_cam_b44"][0].to(device=dev, dtype=torch.float32).contiguous()
+    hint = torch.empty_like(depth)
+    mask_f = torch.empty_like(depth)
+    mask_b = torch.empty(1, 1, h, w, device=dev, dtype=torch.bool)
+    weights = torch.empty_like(depth)
+    X, Y, Z = tsdf.tsdf_weights.shape
+    _abi.check(L.dt_hint_from_depth_f32(_abi.ptr(depth), _abi.ptr(tsdf.tsdf_weights), o, float(tsdf.voxel_size), X, Y, Z,
+                                        _abi.ptr(invK), _abi.ptr(pose), float(weight_threshold), h, w, _abi.ptr(hint),
+                                        _abi.ptr(mask_f), _abi.ptr(mask_b), _abi.ptr(weights), stream), "dt_hint_from_depth_f32")
+    cur_data["depth_hint_b1hw"] = hint
+    cur_data["depth_hint_mask_b_b1hw"] = mask_b
+    cur_data["depth_hint_mask_b1hw"] = mask_f
+    cur_data["sampled_weights_b1hw"] = weights
+    return depth
+
+
 def empty_hint(cur_data, like_b1hw):
     """test_incremental.py:260-269: all-NaN hint, zero mask and weights (first frame / pass 1)."""
     cur_data["depth_hint_b1hw"] = torch.full_like(like_b1hw, float("nan"))

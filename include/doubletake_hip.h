@@ -270,6 +270,21 @@ int dt_mc_generate(const uint16_t* values_f16, const uint32_t* active, int X, in
 int dt_raster_depth_f32(const float* verts_v3, const int64_t* faces_f3, int64_t num_faces,
                         const float* cam_T_world_44, const float* K_44, int h, int w,
                         uint32_t* workspace_hw, float* depth_hw, dt_stream_t s);
+/* The same render for the raw triangle soup of dt_mc_generate (vertex 3f+i of face f, (k,j,i) voxel-index
+ * coordinates; world = origin + (i,j,k)*voxel_size): skips the id sort/unique vertex merge of
+ * utils/pytorch3d_extras.py:90-106, which a depth render does not need.  origin3: HOST pointer. */
+int dt_raster_soup_depth_f32(const float* verts_kji_v3, int64_t num_faces, const float* origin3,
+                             float voxel_size, const float* cam_T_world_44, const float* K_44, int h, int w,
+                             uint32_t* workspace_hw, float* depth_hw, dt_stream_t s);
+/* Hint maps from a rendered depth in one pass (test_incremental.py:204-258): back-project pixel centres
+ * with invK / world_T_cam (device, 16 floats each, row-major 4x4), trilinearly sample the fused
+ * weight volume, keep depth where rendered (!= -1) and weight >= threshold.  Outputs [h,w]:
+ * hint (NaN where dropped), mask (1/0 float), mask_b (1/0 bytes), sampled weights (0 where dropped). */
+int dt_hint_from_depth_f32(const float* depth_hw, const uint16_t* weights_vol_f16, const float* origin3,
+                           float voxel_size, int X, int Y, int Z, const float* invK_44,
+                           const float* world_T_cam_44, float threshold, int h, int w,
+                           float* hint_hw, float* mask_hw, uint8_t* mask_b_hw,
+                           float* sampled_weights_hw, dt_stream_t s);
 
 #ifdef __cplusplus
 }

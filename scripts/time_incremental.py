@@ -14,7 +14,7 @@ import torch
 import bench
 from doubletake_amd.tools.fusers_helper import OurFuser
 from doubletake_amd.utils import synthetic as syn
-from doubletake_amd.utils.rendering_utils import MeshDepthRenderer, empty_hint, prepare_mesh_hint
+from doubletake_amd.utils.rendering_utils import MeshDepthRenderer, empty_hint, prepare_mesh_hint, prepare_mesh_hint_fused
 
 
 def main():
@@ -40,7 +40,10 @@ def main():
         if f == 0:
             empty_hint(cur, torch.zeros(1, 1, H2, W2, device=dev))
         else:
-            prepare_mesh_hint(fuser, renderer, cur, H2, W2)
+            if os.environ.get("DT_HINT_COMPOSED"):
+                prepare_mesh_hint(fuser, renderer, cur, H2, W2)
+            else:
+                prepare_mesh_hint_fused(fuser, cur, H2, W2)
         ev[1].record()
         # frame f + k_src is the new keyframe; its k_src predecessors are the sources (already cached after frame 0)
         cur_img = images[f + k_src:f + k_src + 1]

@@ -113,3 +113,39 @@ def test_incremental_hint_loop_end_to_end():
     # one observation gives weights <= 2.5/100 * conf < 0.025 (tools/tsdf.py:546-549): the reference's
     # 0.025 cut masks everything until a voxel has been seen twice
     assert coverage[0] == 0.0 and coverage[1] == 0.0 and coverage[2] > 0.2
+
+
+def test_fused_hint_preparation_matches_composed_version():
+    """prepare_mesh_hint_fused (soup render + one back-project/sample/threshold kernel) against
+    prepare_mesh_hint (the reference's sequence of torch ops over the merged mesh)."""
+    import gpu_util as gu
+    from doubletake_amd.tools.fusers_helper import OurFuser
+    from doubletake_amd.utils.rendering_utils import MeshDepthRenderer, prepare_mesh_hint, prepare_mesh_hint_fused
+
+    dev = gu.dev()
+    H2, W2 = 96, 128
+    depth, K, T = syn.tsdf_frames(4, H2, W2, seed=5, bounds=BD)
+    depth = depth * np.float32(0.6)
+    fuser = OurFuser(None, 0.04, 3.0, bounds=BD)
+    d, k, t = (torch.from_numpy(a).to(dev) for a in (depth, K, T))
+    for _ in range(3):  # the same views several times so that weights pass the 0.025 cut
+        fuser.fuse_frames(d, k, t, None)
+    for j in (0, 2):
+        mk = lambda: {"K_s0_b44": k[j:j + 1], "invK_s0_b44": torch.linalg.inv(k[j:j + 1]), "cam_T_world_b44": t[j:j + 1],
+                      "world_T_cam_b44": torch.linalg.inv(t[j:j + 1])}
+        a, b = mk(), mk()
+        da = prepare_mesh_hint(fuser, MeshDepthRenderer(H2, W2), a, H2, W2)
+        db = prepare_mesh_hint_fused(fuser, b, H2, W2)
+        covered = (da > 0) & (db > 0)
+        assert covered.float().mean() > 0.3
+        assert ((da > 0) != (db > 0)).float().mean() < 2e-3           # edge pixels only
+        assert (da - db)[covered].abs().max() < 1e-4
+        ma, mb = a["depth_hint_mask_b_b1hw"], b["depth_hint_mask_b_b1hw"]
+        assert mb.dtype == torch.bool and ma.float().mean() > 0.2
+        assert (ma != mb).float().mean() < 2e-3
+        both = ma & mb
+        assert (a["sampled_weights_b1hw"] - b["sampled_weights_b1hw"])[both].abs().max() < 1e-4
+        assert (a["depth_hint_b1hw"] - b["depth_hint_b1hw"])[both].abs().max() < 1e-4
+        assert torch.equal(torch.isnan(b["depth_hint_b1hw"]), ~mb)
+        assert torch.equal(b["depth_hint_mask_b1hw"], mb.float())
+        assert (b["sampled_weights_b1hw"][~mb] == 0).all()
