@@ -138,8 +138,8 @@ __device__ __forceinline__ float hint_mlp_eval_lds(const float* hm, float s, flo
   } while (0)
 
 // NWAVES = 4: one wave per SIMD, up to 512 registers, four accumulator chains in both layers.
-// NWAVES = 8: two waves per SIMD (<= 256 registers each); layer 2 runs in two passes of 64 output
-//             features (two accumulator chains per wave) to fit the register budget.
+// NWAVES = 8: two waves per SIMD (<= 256 registers each); layer 2 runs in four passes of 32 output
+//             features (one accumulator chain) to fit the register budget.
 // A chain of dependent v_mfma_f32_32x32x2_f32 issues at ~1/4 of the pipe rate, so >= 4 independent
 // accumulators must be in flight per SIMD to keep the matrix pipe full.
 template <bool HINT, int NWAVES>
@@ -380,32 +380,29 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
             }
         }
       } else {
+        // four passes of 32 output features, one accumulator chain each: 16 registers less than two chains of
+        // 64 (13 instead of 28 spilled VGPRs at the 256-register cap) and no slower -- a single dependent chain
+        // of 32x32x2 MFMAs already issues back to back (scripts/mfma_chain_bench.hip)
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          f32x16 acc2[2];
-          const float* bl = lds_tail + half * 64 + pass * 32;
+        for (int pass = 0; pass < 4; ++pass) {
+          f32x16 acc2;
+          const float* bl = lds_tail + half * 64 + pass * 16;
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[i][r] = bl[i * 16 + r];
-          const float2* wl = reinterpret_cast<const float2*>(lds_w2 + lane_off + pass * 2);
+          for (int r = 0; r < 16; ++r) acc2[r] = bl[r];
+          const float* wl = lds_w2 + lane_off + pass;
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float2 a2 = wl[(i * 16 + r) * (kStepFloats / 2)];
-              acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, acc1[i][r], acc2[0], 0, 0, 0);
-              acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, acc1[i][r], acc2[1], 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(i * 16 + r) * kStepFloats], acc1[i][r], acc2, 0, 0, 0);
               if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
-          const float* w3 = lds_tail + 128 + half * 64 + pass * 32;
+          const float* w3 = lds_tail + 128 + half * 64 + pass * 16;
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float v2 = acc2[i][r];
-              s += w3[i * 16 + r] * fmaxf(v2, 0.01f * v2);
-            }
+          for (int r = 0; r < 16; ++r) {
+            const float v2 = acc2[r];
+            s += w3[r] * fmaxf(v2, 0.01f * v2);
+          }
         }
       }
       s += __shfl_xor(s, 32, 64);
