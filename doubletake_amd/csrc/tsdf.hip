@@ -148,15 +148,26 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
   // num_frames frames are integrated IN ORDER per voxel (the update is order dependent through the half
   // running mean and the weight clamp, tools/tsdf.py:553-558); the voxel's value/weight stay in registers
   // between frames, rounded to half exactly where the reference stores them.
+  // grid: x over one (j,k) slab of Y*Z voxels (a multiple of 64, so waves never straddle slabs and the
+  // bitmap words stay wave-aligned), y = i.  A slab whose x coordinate lies outside every frame's
+  // frustum box leaves after one scalar test -- on the default +-10 m volume that is most of the grid.
   const size_t total = (size_t)X * Y * Z;
-  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  const unsigned slab = (unsigned)Y * (unsigned)Z;
+  const unsigned pidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const float cx = rh(c.origin[0] + (float)i * c.voxel_size);
+  bool any_x = false;
+  for (int f = 0; f < num_frames; ++f) {
+    const float* fp = fp_all + (size_t)f * kFrameParams;
+    any_x |= (cx > fp[12] && cx < fp[15]);
+  }
+  if (!any_x) return;
+  const size_t id = (size_t)i * slab + pidx;
   bool is_active = false;
-  if (id < total) {
-    const int k = (int)(id % Z);
-    const int j = (int)((id / Z) % Y);
-    const int i = (int)(id / ((size_t)Z * Y));
+  if (pidx < slab) {
+    const int j = (int)(pidx / (unsigned)Z);
+    const int k = (int)(pidx - (unsigned)j * (unsigned)Z);
     // voxel centre: half(fp32(origin) + idx * vs)   (tools/tsdf.py:144-148,164)
-    const float cx = rh(c.origin[0] + (float)i * c.voxel_size);
     const float cy = rh(c.origin[1] + (float)j * c.voxel_size);
     const float cz = rh(c.origin[2] + (float)k * c.voxel_size);
     bool loaded = false, dirty = false;
@@ -352,9 +363,10 @@ int dt_tsdf_integrate_frames_f16(uint16_t* values, uint16_t* weights, uint32_t* 
   c.img_w_h = (float)img_w;  // image extents are exactly representable in half (< 2048)
   c.img_h_h = (float)img_h;
   DT_REQUIRE(img_w <= 2048 && img_h <= 2048, "dt_tsdf_integrate_f16: image extent above 2048 is not exact in half");
-  const size_t blocks = (total + 255) / 256;
-  DT_REQUIRE(blocks < 2147483647ull, "dt_tsdf_integrate_f16: volume too large for one launch");
-  hipLaunchKernelGGL(tsdf_integrate_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(s), values, weights, active, X,
+  const size_t slab = (size_t)Y * Z;
+  DT_REQUIRE(slab % 64 == 0, "dt_tsdf_integrate_f16: Y*Z must be a multiple of 64 (dims are multiples of 8)");
+  DT_REQUIRE(X <= 65535 && slab < 4294967040ull, "dt_tsdf_integrate_f16: volume too large for one launch");
+  hipLaunchKernelGGL(tsdf_integrate_kernel, dim3((unsigned)((slab + 255) / 256), (unsigned)X), dim3(256), 0, to_stream(s), values, weights, active, X,
                      Y, Z, depth, img_h, img_w, frame_params, num_frames, c);
   return check_launch("dt_tsdf_integrate_f16");
 }
