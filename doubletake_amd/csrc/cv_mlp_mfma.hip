@@ -178,11 +178,6 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   const long waves_total = (long)gridDim.x * NWAVES;
   const float b3 = lds_tail[256];
   const bool stage_ok = (D % 8 == 0);  // float4 alignment of the staged NHWC stores
-#if defined(DT_MLP_PRIO)
-  // static priority for the younger half of a two-waves-per-SIMD workgroup: breaks the lock-step
-  // in which both waves of a SIMD reach their gather/VALU phase together and leave the matrix pipe idle
-  if (NWAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(DT_MLP_PRIO);
-#endif
 
   // Balanced static partition: the (batch, tile, plane) units are flattened (plane fastest) and every
   // resident wave takes one contiguous span of floor/ceil(total / waves) units, i.e. one or two
