@@ -52,6 +52,9 @@ SIGNATURES = {
     "dt_conv_pack_floats": (_L, [_I, _I, _I]),
     "dt_conv_pack_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "dt_conv2d_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dt_conv_wino_pack_floats": (_L, [_I, _I]),
+    "dt_conv_wino_pack_f32": (_I, [_P, _P, _I, _I, _P]),
+    "dt_conv2d_wino_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "dt_conv2d_simple_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "dt_conv1x1_head_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "dt_head_mlp_pack_floats": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

@@ -457,6 +457,204 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
   }
 }
 
+// ---- Winograd F(2x2, 3x3) variant of the 3x3 stride-1 conv -------------------------------------------
+// Y = A^T [ (G g G^T) .* (B^T d B) ] A per 4x4 input window / 2x2 output tile: 16 multiplies instead of 36,
+// i.e. 2.25x fewer MFMAs.  Mapping: a workgroup owns 8x16 output pixels = 4x8 Winograd tiles (the MFMA N
+// dimension) of one 32-channel block (M); wave a (of 4) owns row a of the 4x4 transform domain, i.e. the four
+// positions xi = (a, 0..3), one accumulator each.  Per 8-channel group: the 10x18-pixel input patch is staged
+// once in LDS for all four waves (double buffered), every lane reads the two patch rows its transform row
+// combines (8 x ds_read_b128), forms its four B operands with 32 adds, and issues 16 MFMAs against the
+// pre-transformed weights.  Epilogue: column inverse transform in registers, row inverse transform across
+// the four waves through LDS, then wave w writes output sub-pixel (w>>1, w&1) of every tile.
+constexpr int kWinoTH = 4, kWinoTW = 8;                      // Winograd tiles per workgroup (rows, cols)
+constexpr int kWinoPH = 2 * kWinoTH + 2, kWinoPW = 2 * kWinoTW + 2;  // staged input patch 10 x 18
+constexpr int kWinoPatchFloats = kWinoPH * kWinoPW * 8;
+
+__global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
+  constexpr int NPIX = kWinoPH * kWinoPW;  // 180
+  constexpr int NLOAD = (NPIX + 127) / 128;  // float4 staging loads per thread and group
+  __shared__ __attribute__((aligned(16))) float lds[8192];  // 2 patch buffers (2 x 1440) | later: 4 x 2 x 1024 Z values
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, t = lane & 31;
+  const int ty = t >> 3, tx = t & 7;
+
+  const int wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
+  long bid = blockIdx.x;
+  const int cb = (int)(bid % a.co_blocks);
+  bid /= a.co_blocks;
+  const int bx = (int)(bid % wt_x);
+  bid /= wt_x;
+  const int by = (int)(bid % wt_y);
+  const int n = (int)(bid / wt_y);
+  const int iy0 = by * 2 * kWinoTH - 1, ix0 = bx * 2 * kWinoTW - 1;
+
+  int poff0[NLOAD], poff1[NLOAD], poff2[NLOAD];
+#pragma unroll
+  for (int it = 0; it < NLOAD; ++it) {
+    const int idx = (tid >> 1) + it * 128;
+    const int ly = idx / kWinoPW, lx = idx - ly * kWinoPW;
+    int iy = iy0 + ly, ix = ix0 + lx;
+    bool inside = idx < NPIX && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+    if (a.pad_replicate) {
+      iy = min(max(iy, 0), a.h_in - 1);
+      ix = min(max(ix, 0), a.w_in - 1);
+      inside = idx < NPIX;
+    }
+    poff0[it] = pixel_offset(inside, n, iy, ix, a.h_in, a.w_in, a.up[0], a.c[0], tid);
+    poff1[it] = pixel_offset(inside && a.nsrc > 1, n, iy, ix, a.h_in, a.w_in, a.up[1], a.c[1], tid);
+    poff2[it] = pixel_offset(inside && a.nsrc > 2, n, iy, ix, a.h_in, a.w_in, a.up[2], a.c[2], tid);
+  }
+  const int ng0 = a.c[0] >> 3, ng1 = a.c[1] >> 3;
+  const float* src0 = a.src[0];
+  const float* src1 = a.src[1];
+  const float* src2 = a.src[2];
+  // packed weights: [cb][g][xi = 4*row + col][half][32][4]; this wave reads xi = 4*wave .. 4*wave+3
+  const float4* wbase = reinterpret_cast<const float4*>(a.wp) + ((size_t)cb * a.groups * 16 + wave * 4) * 64 + lane;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  // the two patch rows transform row `wave` combines:  0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3
+  const int r1 = (wave == 0) ? 0 : ((wave == 2) ? 2 : 1);
+  const int r2 = (wave == 0) ? 2 : ((wave == 1) ? 2 : ((wave == 2) ? 1 : 3));
+  const float sgn = (wave == 1) ? 1.0f : -1.0f;
+  const int win = ((2 * ty) * kWinoPW + 2 * tx) * 8 + half * 4;  // window origin of this lane's tile in the patch
+
+  float4 patch[NLOAD];
+  float4 w[4];
+#define DTW_PREFETCH(G)                                                                              \
+  do {                                                                                               \
+    const int g_ = (G);                                                                              \
+    const int sidx = (g_ < ng0) ? 0 : ((g_ < ng0 + ng1) ? 1 : 2);                                    \
+    const int gl = (sidx == 0) ? g_ : ((sidx == 1) ? g_ - ng0 : g_ - ng0 - ng1);                     \
+    const float* sp = ((sidx == 0) ? src0 : ((sidx == 1) ? src1 : src2)) + gl * 8;                   \
+    _Pragma("unroll") for (int it = 0; it < NLOAD; ++it) {                                           \
+      const int off = (sidx == 0) ? poff0[it] : ((sidx == 1) ? poff1[it] : poff2[it]);               \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+      if (off >= 0) v = *reinterpret_cast<const float4*>(sp + off);                                  \
+      patch[it] = v;                                                                                 \
+    }                                                                                                \
+    const float4* wg = wbase + (size_t)g_ * (16 * 64);                                               \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) w[b] = wg[b * 64];                                 \
+  } while (0)
+
+  DTW_PREFETCH(0);
+  for (int g = 0; g < a.groups; ++g) {
+    float* buf = lds + (g & 1) * kWinoPatchFloats;
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int idx = (tid >> 1) + it * 128;
+      if (idx < NPIX) *reinterpret_cast<float4*>(buf + idx * 8 + (tid & 1) * 4) = patch[it];
+    }
+    float4 wc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) wc[b] = w[b];
+    __syncthreads();  // patch g visible; everyone is done with buffer (g & 1) from two groups ago
+    if (g + 1 < a.groups) DTW_PREFETCH(g + 1);
+    // B^T d B restricted to transform row `wave`
+    float4 tcol[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 u = *reinterpret_cast<const float4*>(buf + win + (r1 * kWinoPW + c) * 8);
+      const float4 v = *reinterpret_cast<const float4*>(buf + win + (r2 * kWinoPW + c) * 8);
+      tcol[c] = make_float4(u.x + sgn * v.x, u.y + sgn * v.y, u.z + sgn * v.z, u.w + sgn * v.w);
+    }
+    float4 V[4];
+    V[0] = make_float4(tcol[0].x - tcol[2].x, tcol[0].y - tcol[2].y, tcol[0].z - tcol[2].z, tcol[0].w - tcol[2].w);
+    V[1] = make_float4(tcol[1].x + tcol[2].x, tcol[1].y + tcol[2].y, tcol[1].z + tcol[2].z, tcol[1].w + tcol[2].w);
+    V[2] = make_float4(tcol[2].x - tcol[1].x, tcol[2].y - tcol[1].y, tcol[2].z - tcol[1].z, tcol[2].w - tcol[1].w);
+    V[3] = make_float4(tcol[1].x - tcol[3].x, tcol[1].y - tcol[3].y, tcol[1].z - tcol[3].z, tcol[1].w - tcol[3].w);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[b].x, V[b].x, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[b].y, V[b].y, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[b].z, V[b].z, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[b].w, V[b].w, acc[b], 0, 0, 0);
+    }
+  }
+#undef DTW_PREFETCH
+
+  // ---- inverse transform: columns in registers, rows across the four waves through LDS ----------------
+  __syncthreads();  // all waves are done with the patch buffers
+  float* zb = lds + wave * 2048;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float z0 = acc[0][r] + acc[1][r] + acc[2][r];
+    const float z1 = acc[1][r] - acc[2][r] - acc[3][r];
+    zb[(r >> 2) * 256 + lane * 4 + (r & 3)] = z0;
+    zb[1024 + (r >> 2) * 256 + lane * 4 + (r & 3)] = z1;
+  }
+  __syncthreads();
+  const int p = wave >> 1, q = wave & 1;  // output sub-pixel of every tile this wave finishes
+  const int oy = by * 2 * kWinoTH + 2 * ty + p, ox = bx * 2 * kWinoTW + 2 * tx + q;
+  const bool in_image = oy < a.h_out && ox < a.w_out;
+  const size_t pix_off = (((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const float* z = lds + q * 1024 + qd * 256 + lane * 4;
+    const float4 za = *reinterpret_cast<const float4*>(z + (p ? 1 : 0) * 2048);
+    const float4 zbv = *reinterpret_cast<const float4*>(z + (p ? 2 : 1) * 2048);
+    const float4 zc = *reinterpret_cast<const float4*>(z + (p ? 3 : 2) * 2048);
+    float4 o;
+    if (p == 0) {
+      o = make_float4(za.x + zbv.x + zc.x, za.y + zbv.y + zc.y, za.z + zbv.z + zc.z, za.w + zbv.w + zc.w);
+    } else {
+      o = make_float4(za.x - zbv.x - zc.x, za.y - zbv.y - zc.y, za.z - zbv.z - zc.z, za.w - zbv.w - zc.w);
+    }
+    if (in_image) {
+      const int co = cb * 32 + qd * 8 + half * 4;
+      const size_t off = pix_off + co;
+      if (a.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+        o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+      }
+      if (a.res) {
+        const float4 rv = *reinterpret_cast<const float4*>(a.res + off);
+        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+      }
+      o.x = apply_act(o.x, a.act); o.y = apply_act(o.y, a.act); o.z = apply_act(o.z, a.act); o.w = apply_act(o.w, a.act);
+      *reinterpret_cast<float4*>(a.out + off) = o;
+    }
+  }
+}
+
+// OIHW 3x3 weights -> U = G g G^T per (co, ci), packed [co_block][group][xi][half][32][4]
+__global__ void conv_wino_pack_kernel(const float* __restrict__ W, float* __restrict__ packed, int c_out, int c_in) {
+  const int groups = c_in >> 3;
+  const size_t total = (size_t)c_out * c_in * 16;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t r = idx;
+    const int j = r & 3;
+    r >>= 2;
+    const int i = r & 31;
+    r >>= 5;
+    const int h = r & 1;
+    r >>= 1;
+    const int xi = r & 15;
+    r >>= 4;
+    const int g = r % groups;
+    const int cb = (int)(r / groups);
+    const int co = cb * 32 + i, ci = g * 8 + h * 4 + j;
+    const float* k = W + ((size_t)co * c_in + ci) * 9;
+    const int ra = xi >> 2, rb = xi & 3;
+    // row ra of G applied to the kernel columns, then row rb of G
+    float col[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float k0 = k[0 * 3 + c], k1 = k[1 * 3 + c], k2 = k[2 * 3 + c];
+      col[c] = (ra == 0) ? k0 : ((ra == 1) ? 0.5f * (k0 + k1 + k2) : ((ra == 2) ? 0.5f * (k0 - k1 + k2) : k2));
+    }
+    packed[idx] = (rb == 0) ? col[0]
+                            : ((rb == 1) ? 0.5f * (col[0] + col[1] + col[2])
+                                         : ((rb == 2) ? 0.5f * (col[0] - col[1] + col[2]) : col[2]));
+  }
+}
+
 // ---- weight packing: OIHW -> [co_block][group][tap][half][32][4] -----------------------------
 __global__ void conv_pack_kernel(const float* __restrict__ W, float* __restrict__ packed, int c_out, int c_in, int ks) {
   const int taps = ks * ks;
@@ -696,6 +894,34 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
   }
 #undef DT_LAUNCH_CONV
   return check_launch("dt_conv2d_f32");
+}
+
+int64_t dt_conv_wino_pack_floats(int c_out, int c_in) { return (int64_t)c_out * c_in * 16; }
+
+int dt_conv_wino_pack_f32(const float* W, float* packed, int c_out, int c_in, dt_stream_t s) {
+  DT_REQUIRE(W && packed, "dt_conv_wino_pack_f32: null pointer");
+  DT_REQUIRE(c_out > 0 && c_out % 32 == 0, "dt_conv_wino_pack_f32: c_out=%d must be a multiple of 32", c_out);
+  DT_REQUIRE(c_in > 0 && c_in % 8 == 0, "dt_conv_wino_pack_f32: c_in=%d must be a multiple of 8", c_in);
+  const size_t total = (size_t)c_out * c_in * 16;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(conv_wino_pack_kernel, dim3(blocks), dim3(256), 0, to_stream(s), W, packed, c_out, c_in);
+  return check_launch("dt_conv_wino_pack_f32");
+}
+
+int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* packed_w,
+                       const float* bias, const float* residual, float* out, dt_stream_t s) {
+  ConvArgs a;
+  if (int rc = fill_args(d, in0, in1, in2, bias, residual, out, a, "dt_conv2d_wino_f32")) return rc;
+  DT_REQUIRE(packed_w != nullptr, "dt_conv2d_wino_f32: null weights");
+  DT_REQUIRE(d->ksize == 3 && d->stride == 1, "dt_conv2d_wino_f32: only 3x3 stride-1 convolutions (k=%d s=%d)", d->ksize,
+             d->stride);
+  DT_REQUIRE(d->c_out > 0 && d->c_out % 32 == 0, "dt_conv2d_wino_f32: c_out=%d must be a multiple of 32", d->c_out);
+  a.wp = packed_w;
+  const long wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
+  const long blocks = (long)a.n * wt_y * wt_x * a.co_blocks;
+  DT_REQUIRE(blocks < 2147483647L, "dt_conv2d_wino_f32: grid too large");
+  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(s), a);
+  return check_launch("dt_conv2d_wino_f32");
 }
 
 int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* W,

@@ -67,6 +67,32 @@ def packed_weight(conv: nn.Conv2d, device):
     return packed
 
 
+def packed_weight_wino(conv: nn.Conv2d, device):
+    """Winograd-domain weights (G g G^T) of a 3x3 conv, packed for conv_wino_kernel; cached per weight version."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(device))
+    hit = getattr(conv, "_dt_pack_wino", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    co, ci, k, k2 = w.shape
+    if (k, k2) != (3, 3) or conv.stride != (1, 1) or conv.groups != 1 or conv.dilation != (1, 1) or conv.padding != (1, 1):
+        raise NotImplementedError(f"Winograd path needs a 3x3 stride-1 pad-1 conv, got {conv}")
+    L = _abi.lib()
+    wd = w.detach().to(device=device, dtype=torch.float32).contiguous()
+    packed = torch.empty(int(L.dt_conv_wino_pack_floats(co, ci)), device=device, dtype=torch.float32)
+    _abi.check(L.dt_conv_wino_pack_f32(_abi.ptr(wd), _abi.ptr(packed), co, ci, _abi.current_stream(device)),
+               "dt_conv_wino_pack_f32")
+    conv._dt_pack_wino = (key, packed)
+    return packed
+
+
+#: use the Winograd kernel for 3x3 stride-1 layers with at least this many 8x16-pixel x 32-channel workgroups
+#: (set by measurement, see DESIGN.md section 4.2); DT_CONV_WINO_MIN_BLOCKS overrides, 0 disables
+import os as _os  # noqa: E402
+
+WINO_MIN_BLOCKS = int(_os.environ.get("DT_CONV_WINO_MIN_BLOCKS", "256"))
+
+
 def _dev_param(conv, name, device):
     """fp32 device copy of a small parameter (bias / head weight), cached per version."""
     p = getattr(conv, name)
@@ -125,7 +151,15 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
     if residual is not None and (not _is_nhwc(residual) or tuple(residual.shape) != tuple(out.shape)):
         raise ValueError("residual must be NHWC with the output's shape")
     stream = _abi.current_stream(dev)
-    if impl == "mfma":
+    if impl == "mfma" and k == 3 and st == 1 and co % 32 == 0 and WINO_MIN_BLOCKS > 0:
+        wino_blocks = n * ((d.h_out + 7) // 8) * ((d.w_out + 15) // 16) * (co // 32)
+        if wino_blocks >= WINO_MIN_BLOCKS:
+            impl = "wino"
+    if impl == "wino":
+        wp = packed_weight_wino(conv, dev)
+        _abi.check(L.dt_conv2d_wino_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wp), _abi.ptr(bias),
+                                        _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_wino_f32")
+    elif impl == "mfma":
         wp = packed_weight(conv, dev)
         _abi.check(L.dt_conv2d_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wp), _abi.ptr(bias),
                                    _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_f32")

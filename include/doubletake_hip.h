@@ -139,6 +139,14 @@ int dt_conv_pack_f32(const float* W_oihw, float* packed, int c_out, int c_in, in
 int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2,
                   const float* packed_w, const float* bias, const float* residual,
                   float* out, dt_stream_t s);
+/* Winograd F(2x2,3x3) variant for 3x3 stride-1 convolutions (2.25x fewer multiplies; same fp32
+ * arithmetic type, different summation order: results agree with dt_conv2d_f32 to ~1e-6 relative).
+ * packed_w: dt_conv_wino_pack_floats floats made by dt_conv_wino_pack_f32 from the OIHW weight. */
+int64_t dt_conv_wino_pack_floats(int c_out, int c_in);
+int dt_conv_wino_pack_f32(const float* W_oihw, float* packed, int c_out, int c_in, dt_stream_t s);
+int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2,
+                       const float* packed_w, const float* bias, const float* residual,
+                       float* out, dt_stream_t s);
 /* direct (one thread per output element) version of the same primitive taking the
  * unpacked nn.Conv2d weight; GPU-side cross-check for the parity tests. */
 int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in0, const float* in1,

@@ -227,3 +227,31 @@ def test_batched_conv_graph_equals_per_sample():
         one = dec([feats[0][i:i + 1]] + cve(vol[i:i + 1], [f[i:i + 1] for f in feats[1:]]))
         for k in full:
             assert (full[k][i:i + 1] - one[k]).abs().max().item() < 2e-5, k
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 16, 32, 13, 21, "zeros", 1, False),     # ragged extent, one source
+    (2, 24, 64, 16, 32, "zeros", 2, True),      # two sources, the second nearest-upsampled, residual + bias
+    (1, 64, 32, 24, 40, "replicate", 1, False),  # replicate padding
+])
+def test_winograd_conv_vs_direct(shape):
+    """conv_wino_kernel (F(2x2,3x3) on MFMA) against the direct one-thread-per-output conv."""
+    import gpu_util as gu
+    from doubletake_amd.modules import conv_ops as ops
+
+    n, cin, cout, h, w, pad_mode, nsrc, with_res = shape
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1, padding_mode=pad_mode).to(gu.dev())
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(syn.hash_normalish(tuple(conv.weight.shape), 5) * 0.1))
+        conv.bias.copy_(torch.from_numpy(syn.hash_normalish((cout,), 6) * 0.1))
+    if nsrc == 1:
+        srcs = [(ops.as_nhwc(torch.from_numpy(syn.hash_normalish((n, cin, h, w), 1)).to(gu.dev())), False)]
+    else:
+        c0 = cin - 8
+        srcs = [(ops.as_nhwc(torch.from_numpy(syn.hash_normalish((n, c0, h, w), 1)).to(gu.dev())), False),
+                (ops.as_nhwc(torch.from_numpy(syn.hash_normalish((n, 8, h // 2, w // 2), 2)).to(gu.dev())), True)]
+    res = ops.as_nhwc(torch.from_numpy(syn.hash_normalish((n, cout, h, w), 3)).to(gu.dev())) if with_res else None
+    want = ops.conv2d(srcs, conv, act=ops.ACT_LRELU02, residual=res, impl="simple")
+    got = ops.conv2d(srcs, conv, act=ops.ACT_LRELU02, residual=res, impl="wino")
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < 2e-5
