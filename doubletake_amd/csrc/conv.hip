@@ -466,17 +466,27 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
 // combines (8 x ds_read_b128), forms its four B operands with 32 adds, and issues 16 MFMAs against the
 // pre-transformed weights.  Epilogue: column inverse transform in registers, row inverse transform across
 // the four waves through LDS, then wave w writes output sub-pixel (w>>1, w&1) of every tile.
+#ifndef DT_WABL
+#define DT_WABL 0
+#endif
 constexpr int kWinoTH = 4, kWinoTW = 8;                      // Winograd tiles per workgroup (rows, cols)
 constexpr int kWinoPH = 2 * kWinoTH + 2, kWinoPW = 2 * kWinoTW + 2;  // staged input patch 10 x 18
 constexpr int kWinoPatchFloats = kWinoPH * kWinoPW * 8;
 
-__global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
+// KSPLIT > 1: KSPLIT groups of four waves take the 8-channel groups round-robin (each with its own patch
+// buffers) and their partial results are summed in the row-inverse step; for layers with too few output
+// blocks to fill the chip.
+template <int KSPLIT>
+__global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs a) {
   constexpr int NPIX = kWinoPH * kWinoPW;  // 180
   constexpr int NLOAD = (NPIX + 127) / 128;  // float4 staging loads per thread and group
-  __shared__ __attribute__((aligned(16))) float lds[8192];  // 2 patch buffers (2 x 1440) | later: 4 x 2 x 1024 Z values
-  const int tid = threadIdx.x;
+  // per K-split group: 2 patch buffers (2 x 1440 floats), later 4 waves x 2 x 1024 Z values
+  __shared__ __attribute__((aligned(16))) float lds_all[8192 * KSPLIT];
+  const int tid = threadIdx.x & 255;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // transform row of this wave
+  const int ks = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));  // K-split group
+  float* lds = lds_all + ks * 8192;
   const int half = lane >> 5, t = lane & 31;
   const int ty = t >> 3, tx = t & 7;
 
@@ -527,6 +537,10 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
 
   float4 patch[NLOAD];
   float4 w[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) w[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int it = 0; it < NLOAD; ++it) patch[it] = make_float4(0.f, 0.f, 0.f, 0.f);
 #define DTW_PREFETCH(G)                                                                              \
   do {                                                                                               \
     const int g_ = (G);                                                                              \
@@ -536,32 +550,41 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
     _Pragma("unroll") for (int it = 0; it < NLOAD; ++it) {                                           \
       const int off = (sidx == 0) ? poff0[it] : ((sidx == 1) ? poff1[it] : poff2[it]);               \
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
-      if (off >= 0) v = *reinterpret_cast<const float4*>(sp + off);                                  \
+      if (!(DT_WABL & 2) && off >= 0) v = *reinterpret_cast<const float4*>(sp + off);                \
       patch[it] = v;                                                                                 \
     }                                                                                                \
     const float4* wg = wbase + (size_t)g_ * (16 * 64);                                               \
-    _Pragma("unroll") for (int b = 0; b < 4; ++b) w[b] = wg[b * 64];                                 \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                    \
+      w[b] = (DT_WABL & 1) ? make_float4((float)g_, (float)b, 1.f, 2.f) : wg[b * 64];                \
   } while (0)
 
-  DTW_PREFETCH(0);
-  for (int g = 0; g < a.groups; ++g) {
-    float* buf = lds + (g & 1) * kWinoPatchFloats;
+  // every K-split group runs the same number of iterations so that the workgroup barriers line up; a group
+  // whose share is exhausted stages zeros against (re-read, harmless) weights
+  const int iters = (a.groups + KSPLIT - 1) / KSPLIT;
+  if (ks < a.groups) DTW_PREFETCH(ks);
+  for (int i = 0; i < iters; ++i) {
+    const int g = ks + i * KSPLIT;
+    const bool live_g = g < a.groups;
+    float* buf = lds + (i & 1) * kWinoPatchFloats;
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
       const int idx = (tid >> 1) + it * 128;
-      if (idx < NPIX) *reinterpret_cast<float4*>(buf + idx * 8 + (tid & 1) * 4) = patch[it];
+      if (idx < NPIX)
+        *reinterpret_cast<float4*>(buf + idx * 8 + (tid & 1) * 4) = live_g ? patch[it] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float4 wc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) wc[b] = w[b];
-    __syncthreads();  // patch g visible; everyone is done with buffer (g & 1) from two groups ago
-    if (g + 1 < a.groups) DTW_PREFETCH(g + 1);
+    if (!(DT_WABL & 8)) __syncthreads();  // patch visible; everyone is done with this buffer from two iterations ago
+    if (g + KSPLIT < a.groups) DTW_PREFETCH(g + KSPLIT);
     // B^T d B restricted to transform row `wave`
     float4 tcol[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float4 u = *reinterpret_cast<const float4*>(buf + win + (r1 * kWinoPW + c) * 8);
-      const float4 v = *reinterpret_cast<const float4*>(buf + win + (r2 * kWinoPW + c) * 8);
+      const float4 u = (DT_WABL & 4) ? make_float4(acc[0][c], 1.f, 2.f, (float)g)
+                                     : *reinterpret_cast<const float4*>(buf + win + (r1 * kWinoPW + c) * 8);
+      const float4 v = (DT_WABL & 4) ? make_float4(acc[1][c], 3.f, 1.f, (float)c)
+                                     : *reinterpret_cast<const float4*>(buf + win + (r2 * kWinoPW + c) * 8);
       tcol[c] = make_float4(u.x + sgn * v.x, u.y + sgn * v.y, u.z + sgn * v.z, u.w + sgn * v.w);
     }
     float4 V[4];
@@ -594,17 +617,22 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvArgs a) {
   const int oy = by * 2 * kWinoTH + 2 * ty + p, ox = bx * 2 * kWinoTW + 2 * tx + q;
   const bool in_image = oy < a.h_out && ox < a.w_out;
   const size_t pix_off = (((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out;
+  // the 4 channel quads of a tile are dealt to the KSPLIT groups
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const float* z = lds + q * 1024 + qd * 256 + lane * 4;
-    const float4 za = *reinterpret_cast<const float4*>(z + (p ? 1 : 0) * 2048);
-    const float4 zbv = *reinterpret_cast<const float4*>(z + (p ? 2 : 1) * 2048);
-    const float4 zc = *reinterpret_cast<const float4*>(z + (p ? 3 : 2) * 2048);
-    float4 o;
-    if (p == 0) {
-      o = make_float4(za.x + zbv.x + zc.x, za.y + zbv.y + zc.y, za.z + zbv.z + zc.z, za.w + zbv.w + zc.w);
-    } else {
-      o = make_float4(za.x - zbv.x - zc.x, za.y - zbv.y - zc.y, za.z - zbv.z - zc.z, za.w - zbv.w - zc.w);
+  for (int qi = 0; qi < 4 / KSPLIT; ++qi) {
+    const int qd = ks * (4 / KSPLIT) + qi;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k2 = 0; k2 < KSPLIT; ++k2) {
+      const float* z = lds_all + k2 * 8192 + q * 1024 + qd * 256 + lane * 4;
+      const float4 za = *reinterpret_cast<const float4*>(z + (p ? 1 : 0) * 2048);
+      const float4 zbv = *reinterpret_cast<const float4*>(z + (p ? 2 : 1) * 2048);
+      const float4 zc = *reinterpret_cast<const float4*>(z + (p ? 3 : 2) * 2048);
+      if (p == 0) {
+        o.x += za.x + zbv.x + zc.x; o.y += za.y + zbv.y + zc.y; o.z += za.z + zbv.z + zc.z; o.w += za.w + zbv.w + zc.w;
+      } else {
+        o.x += za.x - zbv.x - zc.x; o.y += za.y - zbv.y - zc.y; o.z += za.z - zbv.z - zc.z; o.w += za.w - zbv.w - zc.w;
+      }
     }
     if (in_image) {
       const int co = cb * 32 + qd * 8 + half * 4;
@@ -920,7 +948,13 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
   const long wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
   const long blocks = (long)a.n * wt_y * wt_x * a.co_blocks;
   DT_REQUIRE(blocks < 2147483647L, "dt_conv2d_wino_f32: grid too large");
-  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(s), a);
+  // few output blocks (the 60x80 level and below): split K over two groups of four waves
+  static const int force_split = [] { const char* e = getenv("DT_WINO_KSPLIT"); return e ? atoi(e) : 0; }();
+  const int ksplit = force_split ? force_split : ((blocks < 256 && a.groups >= 8) ? 2 : 1);
+  if (ksplit == 2)
+    hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)blocks), dim3(512), 0, to_stream(s), a);
+  else
+    hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, to_stream(s), a);
   return check_launch("dt_conv2d_wino_f32");
 }
 

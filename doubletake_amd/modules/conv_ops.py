@@ -90,7 +90,7 @@ def packed_weight_wino(conv: nn.Conv2d, device):
 #: (set by measurement); DT_CONV_WINO_MIN_BLOCKS overrides, 0 disables
 import os as _os  # noqa: E402
 
-WINO_MIN_BLOCKS = int(_os.environ.get("DT_CONV_WINO_MIN_BLOCKS", "256"))
+WINO_MIN_BLOCKS = int(_os.environ.get("DT_CONV_WINO_MIN_BLOCKS", "128"))
 
 
 def _dev_param(conv, name, device):
