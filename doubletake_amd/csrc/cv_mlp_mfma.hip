@@ -77,8 +77,14 @@ __device__ __forceinline__ void issue_view(ViewData& v, cfloat_ptr vp,
                                            const float* __restrict__ src_view, float X, float Y, float Z,
                                            float crx, float cry, float crz, int h, int w, float inv_w,
                                            float inv_h, int half) {
+#ifndef DT_MABL
+#define DT_MABL 0
+#endif
   const ViewProj q = project_view(vp, X, Y, Z);
-  const Taps t = bilinear_taps(q.u, q.v, h, w, inv_w, inv_h);
+  Taps t = bilinear_taps(q.u, q.v, h, w, inv_w, inv_h);
+  if (DT_MABL & 1) {  // ablation: every lane gathers the same four texels (L1 hits)
+    t.x0 = 0; t.x1 = 1; t.y0 = 0; t.y1 = 1;
+  }
   const float* p00 = src_view + ((size_t)t.y0 * w + t.x0) * kF + half * 8;
   const float* p01 = src_view + ((size_t)t.y0 * w + t.x1) * kF + half * 8;
   const float* p10 = src_view + ((size_t)t.y1 * w + t.x0) * kF + half * 8;
@@ -107,26 +113,34 @@ __device__ __forceinline__ void issue_view(ViewData& v, cfloat_ptr vp,
   v.ang = crx * v.sx + cry * v.sy + crz * v.sz;
 }
 
-// hint MLP evaluated from LDS with a rolled outer loop: fully unrolled, the 217 weight reads are
-// all issued up front and spill ~100 registers in the two-waves-per-SIMD variant.
-__device__ __forceinline__ float hint_mlp_eval_lds(const float* hm, float s, float hint, float hw) {
-  float a[12];
+// hint MLP [3,12,12,1] evaluated from LDS.  Both lane halves of a wave hold the same pixel, so the 12 hidden
+// units of each layer are split between them (half h owns units 6h..6h+5): layer-1 activations are exchanged
+// with six lane^32 shuffles, layer-2 partial sums with one.  The outer loop stays rolled: fully unrolled, the
+// weight reads are all issued up front and spill ~100 registers in the two-waves-per-SIMD variant.
+// hm: V1[12x3] @0, c1[12] @36, V2[12x12] @48, c2[12] @192, V3[12] @204, c3 @216.
+__device__ __forceinline__ float hint_mlp_eval_lds(const float* hm, float s, float hint, float hw, int half) {
+  const int m0 = half * 6, o0 = 6 - m0;
+  float own[6], oth[6];
 #pragma unroll
-  for (int m = 0; m < 12; ++m)
-    a[m] = lrelu(hm[m * 3 + 0] * s + hm[m * 3 + 1] * hint + hm[m * 3 + 2] * hw + hm[36 + m], 0.01f);
-  float out = hm[216];
-#pragma unroll 1
-  for (int n = 0; n < 12; ++n) {
-    const float4 r0 = *reinterpret_cast<const float4*>(hm + 48 + n * 12);
-    const float4 r1 = *reinterpret_cast<const float4*>(hm + 48 + n * 12 + 4);
-    const float4 r2 = *reinterpret_cast<const float4*>(hm + 48 + n * 12 + 8);
-    float acc = hm[192 + n];
-    acc += r0.x * a[0] + r0.y * a[1] + r0.z * a[2] + r0.w * a[3];
-    acc += r1.x * a[4] + r1.y * a[5] + r1.z * a[6] + r1.w * a[7];
-    acc += r2.x * a[8] + r2.y * a[9] + r2.z * a[10] + r2.w * a[11];
-    out += hm[204 + n] * lrelu(acc, 0.01f);
+  for (int j = 0; j < 6; ++j) {
+    const int m = m0 + j;
+    own[j] = lrelu(hm[m * 3 + 0] * s + hm[m * 3 + 1] * hint + hm[m * 3 + 2] * hw + hm[36 + m], 0.01f);
   }
-  return out;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) oth[j] = __shfl_xor(own[j], 32, 64);
+  float part = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < 6; ++j) {
+    const int n = m0 + j;
+    const float2* ro = reinterpret_cast<const float2*>(hm + 48 + n * 12 + m0);
+    const float2* rx = reinterpret_cast<const float2*>(hm + 48 + n * 12 + o0);
+    const float2 a0 = ro[0], a1 = ro[1], a2 = ro[2], b0 = rx[0], b1 = rx[1], b2 = rx[2];
+    float acc = hm[192 + n];
+    acc += a0.x * own[0] + a0.y * own[1] + a1.x * own[2] + a1.y * own[3] + a2.x * own[4] + a2.y * own[5];
+    acc += b0.x * oth[0] + b0.y * oth[1] + b1.x * oth[2] + b1.y * oth[3] + b2.x * oth[4] + b2.y * oth[5];
+    part += hm[204 + n] * lrelu(acc, 0.01f);
+  }
+  return part + __shfl_xor(part, 32, 64) + hm[216];
 }
 
 #define DT_MFMA4(ACC, A4, BVAL)                                                   \
@@ -406,7 +420,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         const float hint = hmask ? fabsf(hdepth - depth) : -1.f;
         // keep the 217 weight reads inside the plane loop (hoisted, they cost > 100 spilled registers)
         asm volatile("" ::: "memory");
-        s = hint_mlp_eval_lds(lds_tail + kTailFloats, s, hint, hweight);
+        if (!(DT_MABL & 2)) s = hint_mlp_eval_lds(lds_tail + kTailFloats, s, hint, hweight, half);
+        else s += hint * hweight;
       }
       if (!a.out_nhwc) {
         if (live && half == 0) a.vol[((size_t)b * D + d) * hw + pixi] = s;
