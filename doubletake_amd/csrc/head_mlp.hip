@@ -137,6 +137,69 @@ __global__ __launch_bounds__(256, 1) void head_mlp_kernel(const HeadArgs a) {
   }
 }
 
+// Small images (a few hundred pixel tiles): the persistent kernel above would give each wave a single tile,
+// i.e. 384-512 dependent MFMAs behind a 100+ KB weight staging, on a fraction of the CUs.  Here a workgroup
+// owns ONE tile and its four waves split the 128 hidden features (wave w = feature block w): 4x shorter
+// chains, 4x more workgroups, weights read straight from L2 (each wave only needs its quarter).
+template <int NG>
+__global__ __launch_bounds__(256) void head_mlp_split_kernel(const HeadArgs a) {
+  __shared__ float hbuf[4 * 16 * 64];
+  __shared__ float red[4 * 32];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, p = lane & 31;
+  const int lane_off = (half * 32 + p) * 4 + wave;  // this wave's component of the packed float4
+  const long pix = (long)blockIdx.x * 32 + p;
+  const long pc = pix < a.pixels ? pix : a.pixels - 1;
+
+  float4 xq[NG];
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.in + pc * a.cin + half * 4);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) xq[g] = src[g * 2];
+  }
+  // ---- layer A: cin -> this wave's 32 of 128 hidden features -----------------------------------------
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = a.tail[half * 64 + wave * 16 + r];
+  {
+    const float* wl = a.wa + lane_off;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(g * 4 + 0) * kHeadStep], xq[g].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(g * 4 + 1) * kHeadStep], xq[g].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(g * 4 + 2) * kHeadStep], xq[g].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(g * 4 + 3) * kHeadStep], xq[g].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hbuf[(wave * 16 + r) * 64 + lane] = elu1(acc[r]);
+  __syncthreads();
+  // ---- layer B: 128 -> this wave's 32 features; B operands of step (i, r) = block i's row r -----------
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = a.tail[128 + half * 64 + wave * 16 + r];
+  {
+    const float* wl = a.wb + lane_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(i * 16 + r) * kHeadStep], hbuf[(i * 16 + r) * 64 + lane], acc, 0, 0, 0);
+  }
+  // ---- layer C: partial dot over this wave's features, summed across halves and waves -------------------
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += a.tail[256 + half * 64 + wave * 16 + r] * elu1(acc[r]);
+  s += __shfl_xor(s, 32, 64);
+  if (half == 0) red[wave * 32 + p] = s;
+  __syncthreads();
+  if (wave == 0 && half == 0 && pix < a.pixels) {
+    const float v = red[p] + red[32 + p] + red[64 + p] + red[96 + p] + a.tail[384];
+    a.out[pix] = v;
+    if (a.out_exp) a.out_exp[pix] = expf(v);
+  }
+}
+
 static int g_head_cus = 0;
 
 }  // namespace dt
@@ -169,6 +232,14 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
   HeadArgs a;
   a.in = in_nhwc; a.wa = wa; a.wb = wb; a.tail = tail; a.out = out; a.out_exp = out_exp; a.pixels = pixels; a.cin = cin;
   const long tiles = (pixels + 31) / 32;
+  static const long split_max_tiles = [] { const char* e = getenv("DT_HEAD_SPLIT_MAX_TILES"); return e ? atol(e) : 1024L; }();
+  if (tiles <= split_max_tiles) {  // small image: one tile per workgroup, hidden features split over the waves
+    if (cin == 64)
+      hipLaunchKernelGGL(head_mlp_split_kernel<8>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
+    else
+      hipLaunchKernelGGL(head_mlp_split_kernel<16>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
+    return check_launch("dt_head_mlp_f32");
+  }
   const long want = (tiles + 3) / 4;
   const int blocks = (int)(want < g_head_cus ? want : g_head_cus);
   const size_t lds_bytes = (size_t)((cin / 2) * kHeadStep + 64 * kHeadStep + kHeadTail) * sizeof(float);
