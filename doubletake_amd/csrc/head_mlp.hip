@@ -209,7 +209,7 @@ using namespace dt;
 extern "C" {
 
 int dt_head_mlp_pack_floats(int cin, int* wa, int* wb, int* tail) {
-  DT_REQUIRE(cin == 64 || cin == 128, "dt_head_mlp_pack_floats: cin=%d (64 or 128 supported)", cin);
+  DT_REQUIRE(cin == 64 || cin == 128 || cin == 256, "dt_head_mlp_pack_floats: cin=%d (64, 128 or 256 supported)", cin);
   if (wa) *wa = (cin / 2) * kHeadStep;
   if (wb) *wb = 64 * kHeadStep;
   if (tail) *tail = kHeadTail;
@@ -220,7 +220,7 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
                     int64_t pixels, int cin, dt_stream_t s) {
   DT_REQUIRE(in_nhwc && wa && wb && tail && out, "dt_head_mlp_f32: null pointer");
   DT_REQUIRE(pixels > 0, "dt_head_mlp_f32: pixels=%ld", (long)pixels);
-  DT_REQUIRE(cin == 64 || cin == 128, "dt_head_mlp_f32: cin=%d (64 or 128 supported)", cin);
+  DT_REQUIRE(cin == 64 || cin == 128 || cin == 256, "dt_head_mlp_f32: cin=%d (64, 128 or 256 supported)", cin);
   if (g_head_cus <= 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
@@ -236,10 +236,13 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
   if (tiles <= split_max_tiles) {  // small image: one tile per workgroup, hidden features split over the waves
     if (cin == 64)
       hipLaunchKernelGGL(head_mlp_split_kernel<8>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
-    else
+    else if (cin == 128)
       hipLaunchKernelGGL(head_mlp_split_kernel<16>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
+    else
+      hipLaunchKernelGGL(head_mlp_split_kernel<32>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
     return check_launch("dt_head_mlp_f32");
   }
+  DT_REQUIRE(cin != 256, "dt_head_mlp_f32: cin=256 is only supported up to %ld pixel tiles (got %ld)", split_max_tiles, tiles);
   const long want = (tiles + 3) / 4;
   const int blocks = (int)(want < g_head_cus ? want : g_head_cus);
   const size_t lds_bytes = (size_t)((cin / 2) * kHeadStep + 64 * kHeadStep + kHeadTail) * sizeof(float);

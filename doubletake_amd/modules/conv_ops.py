@@ -189,7 +189,7 @@ def conv1x1_head(x, conv: nn.Conv2d, with_exp=False):
 
 def head_mlp(x, head: nn.Sequential, with_exp=False):
     """Fused 1x1 -> ELU -> 1x1 -> ELU -> 1x1 regression head (modules/networks_fast.py:102-132).
-    x NHWC [n,c,h,w] (c = 64 or 128) -> [n,1,h,w]; with_exp: (out, exp(out)) from the same launch."""
+    x NHWC [n,c,h,w] (c = 64, 128, or 256 for small maps) -> [n,1,h,w]; with_exp: (out, exp(out)) from the same launch."""
     from . import mlp_pack
 
     L = _abi.lib()
@@ -214,7 +214,8 @@ def head_mlp(x, head: nn.Sequential, with_exp=False):
 
 def head_mlp_supported(x, head) -> bool:
     try:
-        return (x.shape[1] in (64, 128) and len(head) == 5 and head[0].out_channels == 128 and head[2].out_channels == 128
+        cin_ok = x.shape[1] in (64, 128) or (x.shape[1] == 256 and x.shape[0] * x.shape[2] * x.shape[3] <= 32 * 1024)
+        return (cin_ok and len(head) == 5 and head[0].out_channels == 128 and head[2].out_channels == 128
                 and head[4].out_channels == 1 and all(head[i].kernel_size == (1, 1) for i in (0, 2, 4)))
     except Exception:
         return False

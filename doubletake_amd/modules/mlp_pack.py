@@ -183,8 +183,8 @@ def pack_head_mlp(Wa, ba, Wb, bb, Wc, bc):
     halves (the halves of the float4 each lane loads); layer B uses the accumulator order."""
     Wa = np.asarray(Wa, np.float32).reshape(HID, -1)
     cin = Wa.shape[1]
-    if cin not in (64, 128):
-        raise ValueError("fused head supports 64 or 128 input channels")
+    if cin not in (64, 128, 256):
+        raise ValueError("fused head supports 64, 128 or 256 input channels")
     Wb = np.asarray(Wb, np.float32).reshape(HID, HID)
     tabA = np.zeros((cin // 2, 2), dtype=np.int64)
     for g in range(cin // 8):
