@@ -33,6 +33,7 @@ struct ConvArgs {
   float* out;
   int n, h_out, w_out, c_out, h_in, w_in, act;
   int pad_replicate;  // 1: out-of-image taps read the clamped (edge) pixel instead of zero
+  int xcd_remap;      // 1: XCD-contiguous block order (see xcd_contiguous_block)
   int groups;  // total 8-channel input groups over all sources
   int tiles_x, tiles_y, co_blocks;
 };
@@ -45,6 +46,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 constexpr int kPH = 4, kPW = 8;  // output patch of one MFMA pixel block
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with a private L2).  Map the hardware block index to
+// a logical one so that every XCD works on one contiguous eighth of the block space: the co-blocks of a pixel
+// tile and its neighbouring tiles (shared input halo) then hit the same L2 instead of eight different ones.
+__device__ __forceinline__ long xcd_contiguous_block(int xcd_remap) {
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  if (!xcd_remap || (nb & 7u) != 0u) return (long)b;
+  return (long)(b & 7u) * (nb >> 3) + (b >> 3);
+}
 
 // element offset of input pixel (iy, ix) of image n inside one NHWC source (nearest-upsampled when
 // `up`), plus this lane's 4-channel half of the 8-channel group; -1 = zero padding
@@ -79,7 +89,7 @@ __global__ __launch_bounds__(SPLIT >= 8 ? SPLIT * 64 : 256) void conv_mfma_kerne
   const int py = p >> 3, px = p & 7;
 
   const long total_blocks = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
-  long bid = (SPLIT == 1) ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x;
+  long bid = (SPLIT == 1) ? (long)blockIdx.x * 4 + wave : xcd_contiguous_block(a.xcd_remap);
   const bool have_block = bid < total_blocks;
   if (!have_block) bid = total_blocks - 1;  // keep the wave alive (no barriers are skipped); it stores nothing
   const int cb = (int)(bid % a.co_blocks);
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs 
   const int ty = t >> 3, tx = t & 7;
 
   const int wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
-  long bid = blockIdx.x;
+  long bid = xcd_contiguous_block(a.xcd_remap);
   const int cb = (int)(bid % a.co_blocks);
   bid /= a.co_blocks;
   const int bx = (int)(bid % wt_x);
@@ -846,6 +856,8 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
   a.w_in = d->w_in;
   a.act = d->act;
   a.pad_replicate = d->pad_mode;
+  static const int xcd_remap = [] { const char* e = getenv("DT_CONV_XCD_REMAP"); return e ? atoi(e) : 1; }();
+  a.xcd_remap = xcd_remap;
   a.tiles_x = (d->w_out + kPW - 1) / kPW;
   a.tiles_y = (d->h_out + kPH - 1) / kPH;
   a.co_blocks = d->c_out / 32;
