@@ -70,7 +70,7 @@ def build_model(device):
 
 
 def cpu_baseline_frame(inp, pyr, model):
-    """One frame of the same workload through the numpy oracle.  Returns seconds."""
+    """One frame of the same workload through the numpy oracle.  Returns (seconds, {scale: depth map})."""
     from oracle import cost_volume_ref as cref
     from oracle import networks_ref as nref
 
@@ -85,10 +85,11 @@ def cpu_baseline_frame(inp, pyr, model):
     cref.lowest_cost(vol, planes)
     cv = nref.cv_encoder(vol, pyr[1:], {k[len("cost_volume_net."):]: v for k, v in sd.items() if k.startswith("cost_volume_net.")})
     out = nref.skip_decoder_regression([pyr[0]] + cv, {k[len("depth_decoder."):]: v for k, v in sd.items() if k.startswith("depth_decoder.")})
+    depths = {}
     for k in list(out):
         if k.startswith("log_depth"):
-            np.exp(out[k])
-    return time.perf_counter() - t0
+            depths[k.replace("log_", "")] = np.exp(out[k])
+    return time.perf_counter() - t0, depths
 
 
 def dot_volume_roofline(device, t, launches=30):
@@ -325,7 +326,14 @@ def main():
                 nthreads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
             except Exception:
                 nthreads = 1
-            sec = cpu_baseline_frame(inp, pyr, model)
+            sec, ref_depths = cpu_baseline_frame(inp, pyr, model)
+            # the oracle frame doubles as a full-size parity check of the whole path (checker only, outside
+            # the timed region): north-star tolerance 1e-3 abs depth
+            gpu_out = model_step()
+            torch.cuda.synchronize(device)
+            diffs = {k: float(np.abs(gpu_out[k].cpu().numpy() - v).max()) for k, v in ref_depths.items() if k in gpu_out}
+            result["parity"] = {"checker": "numpy oracle, same inputs and weights, full size", "max_abs_depth_diff": diffs,
+                                "tolerance": 1e-3, "ok": bool(diffs) and max(diffs.values()) < 1e-3}
             result["cpu_baseline"] = {
                 "value": 1.0 / sec,
                 "unit": "frames/s",
