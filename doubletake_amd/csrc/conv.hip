@@ -34,6 +34,7 @@ struct ConvArgs {
   int n, h_out, w_out, c_out, h_in, w_in, act;
   int pad_replicate;  // 1: out-of-image taps read the clamped (edge) pixel instead of zero
   int xcd_remap;      // 1: XCD-contiguous block order (see xcd_contiguous_block)
+  int cb_major;       // 1: channel block is the slowest block coordinate (weight-dominated layers)
   int groups;  // total 8-channel input groups over all sources
   int tiles_x, tiles_y, co_blocks;
 };
@@ -92,8 +93,17 @@ __global__ __launch_bounds__(SPLIT >= 8 ? SPLIT * 64 : 256) void conv_mfma_kerne
   long bid = (SPLIT == 1) ? (long)blockIdx.x * 4 + wave : xcd_contiguous_block(a.xcd_remap);
   const bool have_block = bid < total_blocks;
   if (!have_block) bid = total_blocks - 1;  // keep the wave alive (no barriers are skipped); it stores nothing
-  const int cb = (int)(bid % a.co_blocks);
-  bid /= a.co_blocks;
+  int cb;
+  if (SPLIT != 1 && a.cb_major) {
+    // weight-dominated layers (few pixels, many channels): channel block slowest, so that with the
+    // XCD-contiguous order each XCD's L2 holds the weights of only an eighth of the channel blocks
+    const long px_tiles = (long)a.n * a.tiles_y * a.tiles_x;
+    cb = (int)(bid / px_tiles);
+    bid -= (long)cb * px_tiles;
+  } else {
+    cb = (int)(bid % a.co_blocks);
+    bid /= a.co_blocks;
+  }
   const int tx = (int)(bid % a.tiles_x);
   bid /= a.tiles_x;
   const int ty = (int)(bid % a.tiles_y);
@@ -858,6 +868,9 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
   a.pad_replicate = d->pad_mode;
   static const int xcd_remap = [] { const char* e = getenv("DT_CONV_XCD_REMAP"); return e ? atoi(e) : 1; }();
   a.xcd_remap = xcd_remap;
+  static const int cb_major_mode = [] { const char* e = getenv("DT_CONV_CB_MAJOR"); return e ? atoi(e) : 1; }();
+  // weights (c_out x K x taps) outweigh the input (pixels x K) when pixels < c_out x taps
+  a.cb_major = cb_major_mode && ((long)d->n * d->h_out * d->w_out < (long)d->c_out * d->ksize * d->ksize);
   a.tiles_x = (d->w_out + kPW - 1) / kPW;
   a.tiles_y = (d->h_out + kPH - 1) / kPH;
   a.co_blocks = d->c_out / 32;
