@@ -59,10 +59,35 @@ class MatchingFeatureCache:
 
 
 class DepthModelCVHint(nn.Module):
+    #: option fields the reference constructor reads (experiment_modules/doubletake_model.py:84-204)
+    _OPT_FIELDS = ("image_height", "image_width", "image_encoder_name", "depth_decoder_name", "matching_num_depth_bins",
+                   "matching_scale", "matching_feature_dims", "model_num_views", "min_matching_depth", "max_matching_depth",
+                   "matching_encoder_type")
+
     def __init__(self, image_height=384, image_width=512, image_encoder_name="resnet18d", depth_decoder_name="skip",
                  matching_num_depth_bins=64, matching_scale=1, matching_feature_dims=16, model_num_views=8,
                  min_matching_depth=0.25, max_matching_depth=5.0, matching_encoder_type="resnet"):
+        """Keyword form, or the reference's ``DepthModelCVHint(opts)`` with an options object / namespace that
+        carries the fields of ``_OPT_FIELDS`` (missing ones keep the reference defaults of options.py)."""
         super().__init__()
+        if not isinstance(image_height, int) and hasattr(image_height, "image_height"):
+            opts = image_height
+            for bad, want in (("cv_encoder_type", "multi_scale_encoder"), ("feature_volume_type", "mlp_mesh_hint_feature_volume"),
+                              ("loss_type", "log_l1")):
+                if getattr(opts, bad, want) != want:
+                    raise NotImplementedError(f"{bad}={getattr(opts, bad)!r}: only {want!r} (the DoubleTake configuration) is built")
+            self.run_opts = opts
+            image_height = opts.image_height
+            image_width = getattr(opts, "image_width", image_width)
+            image_encoder_name = getattr(opts, "image_encoder_name", image_encoder_name)
+            depth_decoder_name = getattr(opts, "depth_decoder_name", depth_decoder_name)
+            matching_num_depth_bins = getattr(opts, "matching_num_depth_bins", matching_num_depth_bins)
+            matching_scale = getattr(opts, "matching_scale", matching_scale)
+            matching_feature_dims = getattr(opts, "matching_feature_dims", matching_feature_dims)
+            model_num_views = getattr(opts, "model_num_views", model_num_views)
+            min_matching_depth = getattr(opts, "min_matching_depth", min_matching_depth)
+            max_matching_depth = getattr(opts, "max_matching_depth", max_matching_depth)
+            matching_encoder_type = getattr(opts, "matching_encoder_type", matching_encoder_type)
         key = "efficientnet" if "efficientnet" in image_encoder_name else "resnet18d"
         self.num_ch_enc = list(ENCODER_WIDTHS[key])
         self.matching_scale = matching_scale

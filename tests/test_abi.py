@@ -68,3 +68,27 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_model_accepts_reference_opts_object():
+    """DepthModelCVHint(opts) as the reference constructs it (experiment_modules/doubletake_model.py:84-204)."""
+    import types
+
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
+
+    opts = types.SimpleNamespace(image_height=192, image_width=256, image_encoder_name="resnet18d", depth_decoder_name="skip",
+                                 matching_num_depth_bins=32, matching_scale=1, matching_feature_dims=16, model_num_views=5,
+                                 min_matching_depth=0.25, max_matching_depth=5.0, matching_encoder_type="resnet",
+                                 cv_encoder_type="multi_scale_encoder", feature_volume_type="mlp_mesh_hint_feature_volume",
+                                 loss_type="log_l1")
+    m = DepthModelCVHint(opts)
+    assert m.cost_volume.num_source_views == 4 and m.cost_volume.num_depth_bins == 32
+    assert (m.cost_volume.matching_height, m.cost_volume.matching_width) == (48, 64)
+    keys = list(m.state_dict().keys())
+    assert any(k.startswith("matching_model.net.0.") for k in keys) and any(k.startswith("cost_volume.mlp.") for k in keys)
+    assert any(k.startswith("cost_volume_net.") for k in keys) and any(k.startswith("depth_decoder.") for k in keys)
+    opts.feature_volume_type = "mlp_feature_volume"
+    import pytest
+
+    with pytest.raises(NotImplementedError):
+        DepthModelCVHint(opts)
