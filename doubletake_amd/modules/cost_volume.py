@@ -97,9 +97,26 @@ class CostVolumeManager(nn.Module):
         u, v = pix_coords_bk2hw[:, :, 0], pix_coords_bk2hw[:, :, 1]
         return (u > 2) & (u < self.matching_width - 2) & (v > 2) & (v < self.matching_height - 2)
 
+    @torch.no_grad()
     def generate_depth_planes(self, batch_size, min_depth, max_depth):
-        """cost_volume.py:96-130; computed by dt_cv_setup_f32, returned as an expanded view."""
-        raise NotImplementedError("use forward(); planes are produced by dt_cv_setup_f32")
+        """cost_volume.py:96-130: log-spaced planes [batch, D, h, w] (an expanded view).  Computed by the same
+        dt_cv_setup_f32 launch forward() uses (with identity cameras), so the values are bit-identical to the
+        planes the volume kernels see."""
+        _require_gpu(min_depth, "min_depth")
+        L = _abi.lib()
+        dev = min_depth.device
+        b, D = int(batch_size), self.num_depth_bins
+        eye = torch.eye(4, device=dev, dtype=torch.float32)
+        m1 = eye.repeat(b, 1, 1, 1).contiguous()
+        invK = eye.repeat(b, 1, 1).contiguous()
+        mn = _f32c(min_depth).reshape(-1)
+        mx = _f32c(max_depth.to(dev)).reshape(-1)
+        mn = mn if mn.numel() == b else mn[:1].expand(b).contiguous()
+        mx = mx if mx.numel() == b else mx[:1].expand(b).contiguous()
+        params = torch.empty(b, int(L.dt_cv_params_floats(D, 1)), device=dev, dtype=torch.float32)
+        _abi.check(L.dt_cv_setup_f32(_abi.ptr(m1), _abi.ptr(m1), _abi.ptr(m1), _abi.ptr(invK), _abi.ptr(mn), _abi.ptr(mx),
+                                     b, 1, D, _abi.ptr(params), _abi.current_stream(dev)), "dt_cv_setup_f32")
+        return params[:, 12:12 + D].reshape(b, D, 1, 1).expand(b, D, self.matching_height, self.matching_width)
 
     def indices_to_disparity(self, indices, depth_planes_bdhw):
         return torch.gather(depth_planes_bdhw, 1, indices.unsqueeze(1)).squeeze(1)

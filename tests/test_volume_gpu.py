@@ -199,3 +199,20 @@ def test_other_baseline_configs_mfma_vs_simple_and_oracle_probes(name, b, k, h, 
         want = ref.mlp_forward(np.stack([s, hmap, hwm], -1), hw_).reshape(h, w)
         got = va[bi, d].cpu().numpy()
         assert np.abs(got - want).max() < 5e-5, (name, d)
+
+
+def test_generate_depth_planes_public_method():
+    """cost_volume.py:96-130 as a stand-alone call: equals the oracle's planes and the planes forward() returns."""
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import CostVolumeManager
+    from oracle import cost_volume_ref as ref
+
+    inp = syn.volume_inputs(2, 2, 12, 20, 16, 3)
+    t = gu.to_dev(inp)
+    m = CostVolumeManager(12, 20, num_depth_bins=16).to(gu.dev())
+    planes = m.generate_depth_planes(2, t["min_depth"], t["max_depth"])
+    assert tuple(planes.shape) == (2, 16, 12, 20)
+    want = ref.generate_depth_planes(inp["min_depth"], inp["max_depth"], 16)
+    np.testing.assert_allclose(planes[:, :, 0, 0].cpu().numpy(), want, rtol=3e-6)
+    _, _, fwd_planes, _ = m(**gu.volume_call_args(t))
+    assert torch.equal(planes, fwd_planes)
