@@ -63,6 +63,45 @@ __global__ void cv_setup_kernel(const float* __restrict__ src_Ks, const float* _
 }
 
 // ------------------------------------------------------------------------------------------
+// warp_features (cost_volume.py:132-217) as a stand-alone op: ONE depth map per batch element (any value per
+// pixel), all source views.  One thread per (batch, view, pixel); NCHW in, NCHW out like the reference.
+// The fused volume kernels do not call this -- it exists for callers of the public method.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cv_warp_kernel(const float* __restrict__ src_bkchw, const float* __restrict__ params,
+                                                     const float* __restrict__ depth_bhw, int K, int C, int h, int w,
+                                                     int D, float* __restrict__ world_B4N, float* __restrict__ depths_bkhw,
+                                                     float* __restrict__ warped_bkchw, float* __restrict__ mask_bkhw) {
+  const size_t hw = (size_t)h * w;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.z, k = blockIdx.y;
+  if (idx >= hw) return;
+  const int y = (int)(idx / w), x = (int)(idx % w);
+  const float* p = params + (size_t)b * cv_params_floats(D, K);
+  float rx, ry, rz;
+  pixel_ray(p + kCvInvK, x, y, rx, ry, rz);
+  const float depth = depth_bhw[(size_t)b * hw + idx];
+  const float X = depth * rx, Y = depth * ry, Z = depth * rz;
+  const size_t B = (size_t)b * K + k;
+  float* wp = world_B4N + B * 4 * hw + idx;
+  wp[0] = X;
+  wp[hw] = Y;
+  wp[2 * hw] = Z;
+  wp[3 * hw] = 1.0f;
+  const ViewProj q = project_view(p + cv_view_off(D, k), X, Y, Z);
+  depths_bkhw[B * hw + idx] = q.z;
+  mask_bkhw[B * hw + idx] = (q.z > 0.f) ? 1.0f : 0.0f;
+  const Taps t = bilinear_taps(q.u, q.v, h, w, 1.0f / (float)w, 1.0f / (float)h);
+  const float* sb = src_bkchw + B * C * hw;
+  float* ob = warped_bkchw + B * C * hw + idx;
+  const size_t o00 = (size_t)t.y0 * w + t.x0, o01 = (size_t)t.y0 * w + t.x1, o10 = (size_t)t.y1 * w + t.x0,
+               o11 = (size_t)t.y1 * w + t.x1;
+  for (int c = 0; c < C; ++c) {
+    const float* sc = sb + (size_t)c * hw;
+    ob[(size_t)c * hw] = sc[o00] * t.w00 + sc[o01] * t.w01 + sc[o10] * t.w10 + sc[o11] * t.w11;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // dot-product volume.  One thread per pixel of a 32x8 tile, PC planes per block.
 // Source features are NHWC so one bilinear tap = C contiguous floats (float4 loads).
 // ------------------------------------------------------------------------------------------
@@ -332,6 +371,19 @@ int dt_cv_setup_f32(const float* src_Ks, const float* src_ext, const float* src_
   hipLaunchKernelGGL(cv_setup_kernel, dim3(batch), dim3(64), 0, to_stream(s), src_Ks, src_ext, src_poses, cur_invK,
                      min_depth, max_depth, num_src, num_planes, params_out);
   return check_launch("dt_cv_setup_f32");
+}
+
+int dt_cv_warp_f32(const float* src_bkchw, const float* params, const float* depth_bhw, int batch, int num_src,
+                   int channels, int h, int w, int num_planes, float* world_points_B4N, float* depths_bkhw,
+                   float* warped_bkchw, float* mask_bkhw, dt_stream_t s) {
+  DT_REQUIRE(batch > 0 && num_src > 0 && channels > 0 && h > 0 && w > 0 && num_planes > 0, "dt_cv_warp_f32: bad extents");
+  DT_REQUIRE(src_bkchw && params && depth_bhw && world_points_B4N && depths_bkhw && warped_bkchw && mask_bkhw,
+             "dt_cv_warp_f32: null pointer");
+  const size_t hw = (size_t)h * w;
+  dim3 grid((unsigned)((hw + 255) / 256), num_src, batch);
+  hipLaunchKernelGGL(cv_warp_kernel, grid, dim3(256), 0, to_stream(s), src_bkchw, params, depth_bhw, num_src, channels, h, w,
+                     num_planes, world_points_B4N, depths_bkhw, warped_bkchw, mask_bkhw);
+  return check_launch("dt_cv_warp_f32");
 }
 
 int dt_cv_dot_f32(const float* cur, const float* src, const float* params, float* vol, int batch, int num_src,

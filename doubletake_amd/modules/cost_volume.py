@@ -118,6 +118,35 @@ class CostVolumeManager(nn.Module):
                                      b, 1, D, _abi.ptr(params), _abi.current_stream(dev)), "dt_cv_setup_f32")
         return params[:, 12:12 + D].reshape(b, D, 1, 1).expand(b, D, self.matching_height, self.matching_width)
 
+    @torch.no_grad()
+    def warp_features(self, src_feats, src_extrinsics, src_Ks, cur_invK, depth_plane_b1hw, batch_size, num_src_frames,
+                      num_feat_channels, uv_scale=None):
+        """cost_volume.py:132-217 -> (world_points_B4N, depths [b,k,h,w], src_feat_warped [b,k,c,h,w], mask).
+        Stand-alone form of the warp the fused volume kernels do internally (``uv_scale`` is implied by the
+        matching resolution)."""
+        _require_gpu(src_feats, "src_feats")
+        L = _abi.lib()
+        dev = src_feats.device
+        b, k, c = int(batch_size), int(num_src_frames), int(num_feat_channels)
+        h, w = self.matching_height, self.matching_width
+        src = _f32c(src_feats).view(b, k, c, h, w)
+        Ks = _f32c(src_Ks).view(b, k, 4, 4)
+        ext = _f32c(src_extrinsics).view(b, k, 4, 4)
+        invK = _f32c(cur_invK).view(b, 4, 4)
+        one = torch.ones(b, device=dev, dtype=torch.float32)
+        params = torch.empty(b, int(L.dt_cv_params_floats(1, k)), device=dev, dtype=torch.float32)
+        stream = _abi.current_stream(dev)
+        _abi.check(L.dt_cv_setup_f32(_abi.ptr(Ks), _abi.ptr(ext), _abi.ptr(ext), _abi.ptr(invK), _abi.ptr(one), _abi.ptr(one),
+                                     b, k, 1, _abi.ptr(params), stream), "dt_cv_setup_f32")
+        depth = _f32c(depth_plane_b1hw).view(b, h, w)
+        world = torch.empty(b * k, 4, h * w, device=dev, dtype=torch.float32)
+        depths = torch.empty(b, k, h, w, device=dev, dtype=torch.float32)
+        warped = torch.empty(b, k, c, h, w, device=dev, dtype=torch.float32)
+        mask = torch.empty(b, k, h, w, device=dev, dtype=torch.float32)
+        _abi.check(L.dt_cv_warp_f32(_abi.ptr(src), _abi.ptr(params), _abi.ptr(depth), b, k, c, h, w, 1, _abi.ptr(world),
+                                    _abi.ptr(depths), _abi.ptr(warped), _abi.ptr(mask), stream), "dt_cv_warp_f32")
+        return world, depths, warped, mask
+
     def indices_to_disparity(self, indices, depth_planes_bdhw):
         return torch.gather(depth_planes_bdhw, 1, indices.unsqueeze(1)).squeeze(1)
 

@@ -53,6 +53,14 @@ int dt_cv_setup_f32(const float* src_Ks_bk44, const float* src_extrinsics_bk44,
                     const float* min_depth_b, const float* max_depth_b,
                     int batch, int num_src, int num_planes, float* params_out, dt_stream_t s);
 
+/* replaces: CostVolumeManager.warp_features (modules/cost_volume.py:132-217) as a stand-alone op: warp every
+ * source view to the current view at ONE depth map per batch element.  src NCHW [b,k,c,h,w]; params from
+ * dt_cv_setup_f32 (num_planes = the D it was built with); outputs: world points [b*k,4,h*w], projected depths
+ * [b,k,h,w] (z + 1e-8), warped features [b,k,c,h,w], mask [b,k,h,w] (1.0 where depth > 0).  The fused volume
+ * kernels do not use it. */
+int dt_cv_warp_f32(const float* src_bkchw, const float* params, const float* depth_bhw, int batch,
+                   int num_src, int channels, int h, int w, int num_planes, float* world_points_B4N,
+                   float* depths_bkhw, float* warped_bkchw, float* mask_bkhw, dt_stream_t s);
 /* replaces: CostVolumeManager.build_cost_volume (modules/cost_volume.py:219-315)
  * = warp_features (:132-217) + channel dot + z'>0 mask + sum over views.
  * src_feats_bkhwc is NHWC (use dt_nchw_to_nhwc_f32 with n = b*k).  volume_bdhw is NCHW. */

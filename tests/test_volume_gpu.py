@@ -216,3 +216,25 @@ def test_generate_depth_planes_public_method():
     np.testing.assert_allclose(planes[:, :, 0, 0].cpu().numpy(), want, rtol=3e-6)
     _, _, fwd_planes, _ = m(**gu.volume_call_args(t))
     assert torch.equal(planes, fwd_planes)
+
+
+def test_warp_features_public_method_vs_oracle():
+    """cost_volume.py:132-217 as a stand-alone call (the fused kernels do the same warp internally)."""
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import CostVolumeManager
+    from oracle import cost_volume_ref as ref
+
+    b, k, h, w, c = 2, 3, 19, 27, 16
+    inp = syn.volume_inputs(b, k, h, w, c, 7)
+    t = gu.to_dev(inp)
+    m = CostVolumeManager(h, w, num_depth_bins=8).to(gu.dev())
+    plane = np.array([1.3, 2.1], dtype=np.float32)
+    depth = torch.from_numpy(np.broadcast_to(plane.reshape(b, 1, 1, 1), (b, 1, h, w)).copy()).to(gu.dev())
+    world, depths, warped, mask = m.warp_features(t["src_feats"], t["src_extrinsics"], t["src_Ks"], t["cur_invK"], depth,
+                                                  b, k, c, None)
+    rw, rz, rwarp, rmask, _ = ref.warp_features(inp["src_feats"], inp["src_extrinsics"], inp["src_Ks"], inp["cur_invK"], plane)
+    assert tuple(world.shape) == (b * k, 4, h * w) and tuple(warped.shape) == (b, k, c, h, w)
+    np.testing.assert_allclose(world.cpu().numpy(), rw, rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(depths.cpu().numpy().reshape(b, k, -1), rz, rtol=2e-6, atol=1e-6)
+    assert np.array_equal(mask.cpu().numpy().reshape(b, k, -1), rmask)
+    assert np.abs(warped.cpu().numpy().reshape(b, k, c, -1) - rwarp).max() < 2e-4
