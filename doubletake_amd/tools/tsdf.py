@@ -41,6 +41,19 @@ class Meshes:
         return self._faces[0]
 
 
+def get_frustum_bounds(invK_144, world_T_cam_144, min_depth=0.1, max_depth=10.0, img_h=480, img_w=640):
+    """Axis-aligned world bounds of a camera frustum between two depths (reference tools/tsdf.py:15-50) ->
+    (minbounds_3, maxbounds_3).  Host-level helper in the caller's dtype/device; the integrate kernel computes the
+    same box itself (dt_tsdf_frames_setup_f16)."""
+    uv = invK_144.new_tensor([[0, 0, 1, 1], [img_w, 0, 1, 1], [0, img_h, 1, 1], [img_w, img_h, 1, 1]]).t().unsqueeze(0)
+    rays = torch.matmul(invK_144, uv)  # [1,4,4]: one column per image corner
+    near, far = rays.clone(), rays.clone()
+    near[:, :3] *= min_depth
+    far[:, :3] *= max_depth
+    corners = torch.matmul(world_T_cam_144, torch.cat((near, far), dim=2))[0]  # [4,8]
+    return corners.amin(dim=1)[:3], corners.amax(dim=1)[:3]
+
+
 def _device():
     if not torch.cuda.is_available():
         raise _abi.DoubletakeHipError("doubletake_amd TSDF needs a ROCm GPU (no CPU fallback)")
@@ -185,6 +198,17 @@ class TSDF:
             "final mesh export goes through a scikit-image fork on CPU in the reference (tools/tsdf.py:182-214); "
             "out of scope (SURVEY.md section 8a M2) -- use to_mesh_pytorch3d()")
 
+    def save_mesh(self, savepath, filename):
+        """tools/tsdf.py:257-265 writes ``filename`` (".bin" -> ".ply") under ``savepath``.  The reference meshes with
+        a scikit-image fork on the CPU there; this writes the GPU marching-cubes mesh (to_mesh_pytorch3d)."""
+        import os
+
+        from ..utils.formats import write_ply
+
+        os.makedirs(savepath, exist_ok=True)
+        _, verts, faces = self.to_mesh_pytorch3d(scale_to_world=True)
+        write_ply(os.path.join(savepath, filename).replace(".bin", ".ply"), verts.cpu().numpy(), faces.cpu().numpy())
+
     def save_tsdf(self, filepath):
         """tools/tsdf.py:267-275 (same npz keys)."""
         np.savez_compressed(
@@ -239,6 +263,18 @@ class TSDFFuser:
     tsdf_weights = property(lambda self: self.tsdf.tsdf_weights)
     shape = property(lambda self: self.tsdf.tsdf_values.shape)
     truncation = property(lambda self: self.truncation_size * self.voxel_size)
+    voxel_coords_3hwd = property(lambda self: self.tsdf.voxel_coords_3hwd)
+    #: the reference keeps an open3d HashSet of active voxel keys here; this is the same set as an [N,3] int32 tensor
+    voxel_hashset = property(lambda self: self.tsdf.active_keys())
+
+    def project_to_camera(self, cam_T_world_T_144, K_144, valid_voxels_14N):
+        """tools/tsdf.py:401-412: pixel coordinates and depth of homogeneous world points, [1,3,N] (host-level
+        helper in the inputs' dtype; integrate_depth projects inside its kernel)."""
+        dev = self.tsdf.device
+        P = torch.matmul(K_144.to(dev), cam_T_world_T_144.to(dev))[:, :3]
+        cam = torch.matmul(P, valid_voxels_14N.to(dev))
+        cam[:, :2] = cam[:, :2] / cam[:, 2, None]
+        return cam
 
     def _thresholds(self, extended_neg_truncation):
         trunc = self.truncation

@@ -173,3 +173,43 @@ def test_batched_integrate_equals_frame_by_frame():
     assert torch.equal(a.tsdf_weights.view(torch.int16), b.tsdf_weights.view(torch.int16))
     assert torch.equal(a.voxel_bitmap, b.voxel_bitmap)
     assert (b.tsdf_weights > 0).sum().item() > 1000
+
+
+def test_host_level_helpers_match_reference_semantics(tmp_path):
+    """get_frustum_bounds / project_to_camera / fuser properties / save_mesh (tools/tsdf.py:15-50,257-265,373-412)."""
+    import gpu_util as gu
+    from doubletake_amd.tools.fusers_helper import OurFuser
+    from doubletake_amd.tools.tsdf import get_frustum_bounds
+    from doubletake_amd.utils.formats import read_ply
+
+    vs, maxd, ext, H, W, seed = RUNS["a"]
+    depth, K, T = syn.tsdf_frames(2, H, W, seed=seed, bounds=BD)
+    depth = depth * np.float32(0.6)
+    d, k, t = (torch.from_numpy(a).to(gu.dev()) for a in (depth, K, T))
+    fuser = OurFuser(None, vs, maxd, bounds=BD)
+    fuser.fuse_frames(d, k, t, None)
+    tf = fuser.tsdf_fuser_pred
+    # frustum box: every corner of the near/far planes lies inside it and it is tight
+    invK, pose = torch.linalg.inv(k[0:1]), torch.linalg.inv(t[0:1])
+    lo, hi = get_frustum_bounds(invK, pose, 0.5, 3.0, H, W)
+    uv = torch.tensor([[0, 0, 1, 1], [W, 0, 1, 1], [0, H, 1, 1], [W, H, 1, 1]], dtype=torch.float32, device=gu.dev()).t()
+    pts = []
+    for dd in (0.5, 3.0):
+        c = invK[0] @ uv
+        c[:3] *= dd
+        pts.append((pose[0] @ c)[:3])
+    pts = torch.cat(pts, 1)
+    assert torch.allclose(lo, pts.amin(1), atol=1e-5) and torch.allclose(hi, pts.amax(1), atol=1e-5)
+    # project_to_camera: the principal ray at depth 2 m lands on the principal point with z = 2
+    centre = torch.tensor([[k[0, 0, 2]], [k[0, 1, 2]], [1.0], [1.0]], device=gu.dev())
+    X = invK[0] @ centre
+    X[:3] *= 2.0
+    world = (pose[0] @ X).unsqueeze(0)
+    cam = tf.project_to_camera(t[0:1], k[0:1], world)
+    assert torch.allclose(cam[0, :, 0], torch.stack([k[0, 0, 2], k[0, 1, 2], torch.tensor(2.0, device=gu.dev())]), atol=1e-3)
+    assert abs(tf.truncation - 3 * vs) < 1e-9 and tuple(tf.voxel_coords_3hwd.shape[1:]) == tuple(tf.shape)
+    keys = tf.voxel_hashset
+    assert keys.shape[1] == 3 and keys.shape[0] > 100
+    fuser.tsdf_fuser_pred.tsdf.save_mesh(str(tmp_path), "scene.bin")
+    v, f = read_ply(str(tmp_path / "scene.ply"))
+    assert v.shape[0] > 100 and f.max() < v.shape[0]
