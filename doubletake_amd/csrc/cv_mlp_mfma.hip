@@ -174,7 +174,22 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
     for (int i = threadIdx.x; i < n_dyn / 4; i += NT) l1[i] = g1[i];
     const float4* g2 = reinterpret_cast<const float4*>(a.w2p);
     float4* l2 = reinterpret_cast<float4*>(lds_w2);
-    for (int i = threadIdx.x; i < kW2Floats / 4; i += NT) l2[i] = g2[i];
+    if (NWAVES == 4) {
+      for (int i = threadIdx.x; i < kW2Floats / 4; i += NT) l2[i] = g2[i];
+    } else {
+      // pass-major layout for the four single-chain layer-2 passes: [pass][step/4][lane][step%4], so that a
+      // lane reads four consecutive K steps of its pass with one conflict-free ds_read_b128 (reading one
+      // component of the packed [step][lane][4 blocks] rows put 64 lanes on 16 LDS banks)
+      for (int i = threadIdx.x; i < kW2Floats / 4; i += NT) {
+        const float4 v = g2[i];
+        const int t = i >> 6, ln = i & 63;  // K step, lane slot
+        float* d = lds_w2 + (t >> 2) * 256 + ln * 4 + (t & 3);
+        d[0 * 16 * 256] = v.x;
+        d[1 * 16 * 256] = v.y;
+        d[2 * 16 * 256] = v.z;
+        d[3 * 16 * 256] = v.w;
+      }
+    }
     const float4* g3 = reinterpret_cast<const float4*>(a.tail);
     float4* l3 = reinterpret_cast<float4*>(lds_tail);
     for (int i = threadIdx.x; i < kTailFloats / 4; i += NT) l3[i] = g3[i];
@@ -398,13 +413,17 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
           const float* bl = lds_tail + half * 64 + pass * 16;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc2[r] = bl[r];
-          const float* wl = lds_w2 + lane_off + pass;
+          const float4* wl = reinterpret_cast<const float4*>(lds_w2 + pass * 16 * 256 + lane_off);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(i * 16 + r) * kStepFloats], acc1[i][r], acc2, 0, 0, 0);
-              if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            for (int rq = 0; rq < 4; ++rq) {
+              const float4 a4 = wl[(i * 4 + rq) * 64];
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, acc1[i][rq * 4 + 0], acc2, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, acc1[i][rq * 4 + 1], acc2, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, acc1[i][rq * 4 + 2], acc2, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, acc1[i][rq * 4 + 3], acc2, 0, 0, 0);
+              if (rq & 1) __builtin_amdgcn_sched_barrier(0);
             }
           const float* w3 = lds_tail + 128 + half * 64 + pass * 16;
 #pragma unroll
