@@ -20,7 +20,10 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "libdoubletake_hip.so")
 HASHFILE = os.path.join(LIBDIR, "build_hash.txt")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# -fno-slp-vectorize: hipcc otherwise packs adjacent scalar fp32 ops into v_pk_mul/v_pk_fma/v_pk_add_f32, which
+# cost extra issue cycles beside MFMAs on gfx950 (MI355X_MICROARCH.md, "price of one filler beside MFMAs");
+# measured on the volume kernel: 0.807 -> 0.795 ms
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-slp-vectorize"]
 # per-file extras.  tsdf.hip restates the reference's half pipeline op by op: fusing a multiply
 # and an add of two different reference ops into one FMA would drop a rounding, so contraction is
 # off for the whole file (hipcc's default is fast-honor-pragmas).
