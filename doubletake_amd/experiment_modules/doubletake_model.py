@@ -32,6 +32,7 @@ class MatchingFeatureCache:
         from collections import OrderedDict
 
         self.capacity = capacity
+        self.token = None  # (weights version, image shape, device) the entries were computed with
         self._store = OrderedDict()
         self.hits = 0
         self.misses = 0
@@ -118,14 +119,18 @@ class DepthModelCVHint(nn.Module):
 
     @torch.no_grad()
     def compute_matching_feats(self, cur_image, src_image, unbatched_matching_encoder_forward=False, cur_ids=None,
-                               src_ids=None):
+                               src_ids=None, scan_ids=None):
         """doubletake_model.py:206-262: matching features of the current image [b,3,H,W] and the source
         images [b,K,3,H,W] -> ([b,C,h,w], [b,K,C,h,w]).  Batched: all b*(1+K) images in one pass.
 
         Extension ("cross-frame feature caching"): with ``cur_ids`` (b frame-id strings)
         and ``src_ids`` (K lists of b strings, the layout of ``src_data["frame_id_string"]``) features are
         kept in an HBM-resident LRU cache and only frames not seen before go through the encoder -- in a
-        scan every keyframe is encoded once instead of once per tuple it appears in.  Features of a cached
+        scan every keyframe is encoded once instead of once per tuple it appears in.  Frame ids repeat across
+        scans ("000012" exists in every ScanNet scan), so entries are keyed by (scan id, frame id): pass
+        ``scan_ids`` (one string, or b strings) whenever one model instance serves more than one scan.  The cache
+        empties itself when the matching encoder's weights change (load_state_dict, in-place update, .to()).
+        Features of a cached
         frame were computed in a different batch, so they can differ from the batched result in the last
         bits (different K-split of the same fp32 sums), exactly like the reference's unbatched flag."""
         if self.matching_model is None:
@@ -135,8 +140,15 @@ class DepthModelCVHint(nn.Module):
         flat = frames.flatten(0, 1)
         if cur_ids is not None and src_ids is not None:
             ids = [[cur_ids[i]] + [src_ids[k][i] for k in range(m - 1)] for i in range(b)]
-            flat_ids = [fid for row in ids for fid in row]
+            scans = [scan_ids] * b if isinstance(scan_ids, str) or scan_ids is None else list(scan_ids)
+            flat_ids = [(scans[i], fid) for i, row in enumerate(ids) for fid in row]
             cache = self.matching_feature_cache
+            # entries are only valid for the weights (and the image size) they were computed with
+            token = (tuple((p.data_ptr(), p._version) for p in self.matching_model.parameters()), tuple(flat.shape[1:]),
+                     str(flat.device))
+            if cache.token != token:
+                cache.clear()
+                cache.token = token
             missing = [j for j, fid in enumerate(flat_ids) if fid not in cache]
             first = {}
             for j in missing:  # the same new frame may appear twice in one batch

@@ -1,25 +1,38 @@
 """Multi-GPU partitioning of the hot path (no reference counterpart -- the
 reference has no multi-GPU inference).
 
-One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Keyframes are sharded
-across ranks; model evaluations are independent, only the TSDF accumulation couples them.  After
-each step every rank all-gathers the compact form of its TSDF update -- the predicted depth map
-plus K and cam_T_world, packed into ONE fp16 buffer -- and integrates the gathered frames of ALL
-ranks into its replica TSDF in canonical (rank-major) frame order.  Integration order is fixed
-because the fp16 running mean and the weight clamp make it order dependent
-(reference tools/tsdf.py:553-558), so every replica stays bit-identical to a serial run over the
-same frame sequence.
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Three modes:
 
-Payload per rank and step: (h*w + 32) halves (ScanNet depth-res 240x320: 154 KB) -> latency-bound;
-a direct all_gather is one hop on the fully connected xGMI mesh.
+* **keyframe-batch shard** (throughput bench, offline two-pass -- 8e rows 1 and 3).  Keyframe batches
+  are dealt round-robin (rank r takes batches r, r+W, ...).  Model evaluations are independent; only the
+  TSDF accumulation couples them.  After each step every rank all-gathers the compact form of its TSDF
+  update -- the predicted depth map plus K and cam_T_world, packed into ONE fp16 buffer -- and integrates
+  the gathered frames of ALL ranks into its replica TSDF in canonical order (step-major, then rank =
+  the serial batch order).  The order is fixed because the fp16 running mean and the weight clamp make
+  integration order dependent (reference tools/tsdf.py:553-558), so every replica stays bit-identical
+  to a single-GPU run over the same batch sequence.  ``run_sharded_pass`` / ``run_two_pass`` are the
+  loops of reference test_offline_two_pass.py:26-131 (first pass) and :292-500 (second pass) in this form.
+* **scene shard** (incremental mode -- 8e row 2).  Inside a scan frame t needs TSDF(t-1)
+  (reference test_incremental.py:187-252,358-372), so scans -- not frames -- are dealt to ranks
+  (``shard_scenes``: longest-processing-time by frame count).  No data-path collective; each finished
+  scan's TSDF (values + weights, fp16, variable extent) goes to rank 0 with a size-then-padded
+  all_gather (``gather_variable``) for export, in rounds so that the collectives match.
+* world == 1: nothing is exchanged and no packing kernel runs.
+
+Payload per rank and step of the keyframe shard: b*(h*w + 32) halves (ScanNet depth-res 240x320:
+154 KB per frame) -> latency-bound; a direct all_gather is one hop on the fully connected xGMI mesh.
 """
 from __future__ import annotations
 
 import numpy as np
 import torch
 import torch.distributed as dist
+import torch.nn.functional as F
 
 
+# ---------------------------------------------------------------------------------------------------
+# keyframe-batch shard
+# ---------------------------------------------------------------------------------------------------
 def pack_update(depth_b1hw: torch.Tensor, K_b44: torch.Tensor, cam_T_world_b44: torch.Tensor) -> torch.Tensor:
     """[b,1,h,w] depth + [b,4,4] K + [b,4,4] T -> [b, h*w + 32] fp16 (the casts OurFuser.fuse_frames applies)."""
     b = depth_b1hw.shape[0]
@@ -39,10 +52,14 @@ def shard_keyframes(num_frames: int, world: int, rank: int):
     return list(range(rank, num_frames, world))
 
 
+def _collective_ready():
+    return dist.is_available() and dist.is_initialized()
+
+
 def exchange_updates(local: torch.Tensor, world: int, force_collective: bool = False) -> torch.Tensor:
     """all_gather of the packed updates -> [world * b, n] in rank-major (canonical) order.
     force_collective: issue the collective even for world == 1 (single-GPU check of the RCCL path)."""
-    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
+    if world == 1 and not (force_collective and _collective_ready()):
         return local
     out = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())  # concatenation along dim 0 = rank-major order
@@ -50,60 +67,207 @@ def exchange_updates(local: torch.Tensor, world: int, force_collective: bool = F
 
 
 class KeyframeShardFuser:
-    """Replica TSDF + per-step exchange.  ``fuse_fn(depth_b1hw, K_b44, T_b44)`` defaults to the HIP
-    OurFuser over an 8 x 8 x 3.2 m volume at 0.04 m / 3 m (the hint fuser of the two-pass driver,
-    reference test_offline_two_pass.py:48-53)."""
+    """Replica TSDF + per-step exchange.
 
-    BOUNDS = dict(xmin=-4.0, xmax=4.0, ymin=-4.0, ymax=4.0, zmin=0.0, zmax=3.2)
+    ``fuse_fn(depth_n1hw, K_n44, T_n44)`` integrates n frames in the given order; by default it is
+    ``fuser.fuse_frames`` of the HIP ``OurFuser`` passed as ``fuser``.  ``depth_hw`` is the size of the depth maps
+    that travel (every rank must use the same); ``upsample_to=(H, W)`` applies the drivers' nearest-neighbour
+    upsampling to the ground-truth depth size (reference test_offline_two_pass.py:97-101) AFTER the exchange, so
+    only the predicted resolution crosses xGMI.
+    """
 
-    def __init__(self, device, world, rank, image_h, image_w, fuse_fn=None, pool=64, resolution=0.04, max_depth=3.0,
-                 force_collective=False):
-        from .utils import synthetic as syn
-
-        self.world, self.rank, self.device = world, rank, device
-        self.force_collective = force_collective
-        self.h, self.w = image_h // 2, image_w // 2  # depth_pred_s0 resolution
-        self.fuser = None
+    def __init__(self, device, world, rank, depth_hw, fuser=None, fuse_fn=None, force_collective=False, upsample_to=None):
+        self.world, self.rank, self.device = int(world), int(rank), device
+        self.force_collective = bool(force_collective)
+        self.h, self.w = int(depth_hw[0]), int(depth_hw[1])
+        self.upsample_to = None if upsample_to is None else (int(upsample_to[0]), int(upsample_to[1]))
+        self.fuser = fuser
         if fuse_fn is None:
-            from .tools.fusers_helper import OurFuser
-
-            self.fuser = OurFuser(gt_path=None, fusion_resolution=resolution, max_fusion_depth=max_depth,
-                                  bounds=self.BOUNDS)
-            fuse_fn = lambda d, K, T: self.fuser.fuse_frames(d, K, T, None)
+            if fuser is None:
+                raise ValueError("KeyframeShardFuser needs a fuser or a fuse_fn")
+            fuse_fn = lambda d, K, T: fuser.fuse_frames(d, K, T, None)
         self.fuse_fn = fuse_fn
-        # synthetic camera path (closed form), resident on the device
-        _, K, T = syn.tsdf_frames(pool, self.h, self.w, seed=5, bounds=self.BOUNDS)
-        self.K_pool = torch.from_numpy(K).to(device)
-        self.T_pool = torch.from_numpy(T).to(device)
-        self.K_pool16 = self.K_pool.half()
-        self.T_pool16 = self.T_pool.half()
-        self.KT_pool16 = torch.cat([self.K_pool16.reshape(pool, 16), self.T_pool16.reshape(pool, 16)], 1).contiguous()
-        self.pool = pool
         self._local = None
         self._all = None
+        self.frames_fused = 0
 
-    def exchange_and_fuse(self, depth_b1hw: torch.Tensor, frame_idx: int):
-        b = depth_b1hw.shape[0]
-        gidx = [(frame_idx * self.world + self.rank) * b + i for i in range(b)]
-        if self.world == 1 and b == 1 and not self.force_collective:
-            # single GPU: nothing to exchange -- integrate the own frame directly (no packing kernels)
-            j = gidx[0] % self.pool
-            self.fuse_fn(depth_b1hw, self.K_pool16[j:j + 1], self.T_pool16[j:j + 1])
-            return 1
-        # pack into a preallocated fp16 buffer: one converting copy for the depth, one for [K | T]
-        n = self.h * self.w
-        if self._local is None or self._local.shape[0] != b:
-            self._local = torch.empty((b, n + 32), dtype=torch.float16, device=self.device)
-            self._all = torch.empty((self.world * b, n + 32), dtype=torch.float16, device=self.device)
-        self._local[:, :n].copy_(depth_b1hw.reshape(b, n))
-        for i, g in enumerate(gidx):
-            j = g % self.pool
-            self._local[i, n:].copy_(self.KT_pool16[j])
-        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
-            allbuf = self._local
-        else:
-            dist.all_gather_into_tensor(self._all, self._local)  # rank-major = canonical frame order
-            allbuf = self._all
-        depth, K, T = unpack_update(allbuf, self.h, self.w)
+    def _fuse(self, depth, K, T):
+        if self.upsample_to is not None and tuple(depth.shape[-2:]) != self.upsample_to:
+            depth = F.interpolate(depth.float(), size=self.upsample_to, mode="nearest").to(depth.dtype)
         self.fuse_fn(depth, K, T)
-        return depth.shape[0]
+        self.frames_fused += int(depth.shape[0])
+
+    def exchange_and_fuse(self, depth_b1hw, K_b44, cam_T_world_b44, counts=None, rows=None):
+        """One step.  ``depth_b1hw`` [b,1,h,w] with its cameras ([b,4,4] each, any float dtype; cast to half like
+        OurFuser.fuse_frames), or None when this rank has no batch in this step.  ``counts``: the number of frames
+        every rank contributes in this step (length world; known from the schedule, so no flag travels); default =
+        every rank contributes b.  ``rows``: rows of the exchange buffer (max batch size), default max(counts).
+        Returns the number of frames integrated."""
+        b = 0 if depth_b1hw is None else int(depth_b1hw.shape[0])
+        if counts is None:
+            counts = [b] * self.world
+        if len(counts) != self.world or counts[self.rank] != b:
+            raise ValueError(f"counts {counts} does not match world {self.world} / this rank's batch of {b}")
+        if b and tuple(depth_b1hw.shape[-2:]) != (self.h, self.w):
+            raise ValueError(f"depth maps are {tuple(depth_b1hw.shape[-2:])}, the exchange was set up for {(self.h, self.w)}")
+        collective = self.world > 1 or (self.force_collective and _collective_ready())
+        if not collective:
+            if b:  # single GPU: nothing to exchange -- integrate the own frames directly (no packing kernels)
+                self._fuse(depth_b1hw, K_b44, cam_T_world_b44)
+            return b
+        rows = max(counts) if rows is None else int(rows)
+        if rows == 0:
+            return 0
+        n = self.h * self.w
+        if self._local is None or self._local.shape[0] != rows:
+            self._local = torch.zeros((rows, n + 32), dtype=torch.float16, device=self.device)
+            self._all = torch.empty((self.world * rows, n + 32), dtype=torch.float16, device=self.device)
+        if b:  # converting copies straight into the send buffer: depth, then [K | T]
+            self._local[:b, :n].copy_(depth_b1hw.reshape(b, n))
+            self._local[:b, n:n + 16].copy_(K_b44.reshape(b, 16))
+            self._local[:b, n + 16:].copy_(cam_T_world_b44.reshape(b, 16))
+        dist.all_gather_into_tensor(self._all, self._local)  # rank-major = canonical batch order
+        if all(c == rows for c in counts):
+            sel = self._all
+        else:  # ragged tail of the schedule: drop the padding rows (host-known indices, no sync)
+            idx = [r * rows + i for r, c in enumerate(counts) for i in range(c)]
+            sel = self._all[torch.as_tensor(idx, device=self._all.device)]
+        depth, K, T = unpack_update(sel, self.h, self.w)
+        self._fuse(depth, K, T)
+        return int(depth.shape[0])
+
+
+def run_sharded_pass(num_batches, batch_size_of, step_fn, shard_fuser: KeyframeShardFuser):
+    """One pass over a scan's keyframe batches, sharded over the ranks (the loop of reference
+    test_offline_two_pass.py:76-126 / :300-470 with the fuser call replaced by exchange + replica integrate).
+
+    ``step_fn(batch_index) -> (depth_b1hw, K_b44, cam_T_world_b44)`` evaluates one batch (hint preparation + model);
+    it only runs for this rank's batches.  ``batch_size_of(i)`` is the number of keyframes in batch i (all ranks know
+    the dataloader's length and batch size; the last batch may be short).  Returns the number of frames integrated
+    into the replica (= all frames of the scan, on every rank)."""
+    world, rank = shard_fuser.world, shard_fuser.rank
+    sizes = [int(batch_size_of(i)) for i in range(num_batches)]
+    rows = max(sizes) if sizes else 0
+    total = 0
+    for s in range((num_batches + world - 1) // world):
+        counts = [sizes[s * world + r] if s * world + r < num_batches else 0 for r in range(world)]
+        mine = s * world + rank
+        depth = K = T = None
+        if mine < num_batches:
+            depth, K, T = step_fn(mine)
+        total += shard_fuser.exchange_and_fuse(depth, K, T, counts=counts, rows=rows)
+    return total
+
+
+def run_two_pass(num_batches, batch_size_of, first_pass_fn, second_pass_fn, hint_shard_fuser, final_shard_fuser,
+                 between_passes=None):
+    """Offline two-pass over one scan (reference test_offline_two_pass.py:26-131 then :292-500).
+
+    Pass 1 (``first_pass_fn``: model with empty hints) fills every rank's replica of the 0.04 m / 3 m hint TSDF
+    (``hint_shard_fuser``; reference :48-53).  The replicas are bit-identical, so the hint mesh
+    (``get_mesh_pytorch3d``, reference :129) is extracted locally on every rank -- no collective --
+    in ``between_passes(hint_fuser)`` whose result is handed to ``second_pass_fn(batch_index, hint_state)``.
+    Pass 2 renders hints from that mesh, samples the hint TSDF's weights, runs the model and fuses into the final
+    volume (``final_shard_fuser``, may be None when fusion is off)."""
+    n1 = run_sharded_pass(num_batches, batch_size_of, first_pass_fn, hint_shard_fuser)
+    state = between_passes(hint_shard_fuser.fuser) if between_passes is not None else None
+    if final_shard_fuser is None:
+        mine = shard_keyframes(num_batches, hint_shard_fuser.world, hint_shard_fuser.rank)
+        for i in mine:
+            second_pass_fn(i, state)
+        return n1, 0
+    n2 = run_sharded_pass(num_batches, batch_size_of, lambda i: second_pass_fn(i, state), final_shard_fuser)
+    return n1, n2
+
+
+# ---------------------------------------------------------------------------------------------------
+# scene shard (incremental mode)
+# ---------------------------------------------------------------------------------------------------
+def shard_scenes(frame_counts, world: int):
+    """Deal scans to ranks, longest first onto the least loaded rank (ties -> lowest rank / lowest scan index):
+    deterministic, and within 4/3 of the optimal makespan.  Returns ``world`` lists of scan indices, each in
+    the order that rank processes them."""
+    order = sorted(range(len(frame_counts)), key=lambda i: (-int(frame_counts[i]), i))
+    load = [0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        out[r].append(i)
+        load[r] += int(frame_counts[i])
+    return out
+
+
+_HDR = 8  # int32 words: X, Y, Z, scene index, origin.x/y/z (fp32 bits), voxel size (fp32 bits)
+
+
+def pack_tsdf(values: torch.Tensor, weights: torch.Tensor, origin_f32, voxel_size: float, scene_index: int) -> torch.Tensor:
+    """fp16 values + weights [X,Y,Z] and the volume's placement -> one flat byte buffer (bit copies, nothing rounds;
+    uint8 because it is an element type both RCCL and gloo move)."""
+    X, Y, Z = values.shape
+    hdr = np.zeros(_HDR, dtype=np.int32)
+    hdr[:4] = (X, Y, Z, scene_index)
+    hdr[4:7] = np.asarray(origin_f32, dtype=np.float32).view(np.int32)
+    hdr[7] = np.float32(voxel_size).view(np.int32)
+    h8 = torch.from_numpy(hdr.view(np.uint8).copy()).to(values.device)
+    return torch.cat([h8, values.contiguous().half().reshape(-1).view(torch.uint8),
+                      weights.contiguous().half().reshape(-1).view(torch.uint8)])
+
+
+def unpack_tsdf(buf: torch.Tensor):
+    hdr = buf[: 4 * _HDR].cpu().numpy().view(np.int32)
+    X, Y, Z, scene = (int(v) for v in hdr[:4])
+    n = 2 * X * Y * Z  # bytes per volume
+    body = buf[4 * _HDR: 4 * _HDR + 2 * n]
+    return dict(scene_index=scene, origin_f32=hdr[4:7].copy().view(np.float32), voxel_size=float(hdr[7:8].copy().view(np.float32)[0]),
+                tsdf_values=body[:n].view(torch.float16).reshape(X, Y, Z), tsdf_weights=body[n:].view(torch.float16).reshape(X, Y, Z))
+
+
+def gather_variable(payload: torch.Tensor, world: int, dst: int = 0, rank: int = 0):
+    """Variable-size gather as two all_gathers: element counts first, then the payloads padded to the largest.
+    ``payload`` is 1-D (may be empty).  Returns the list of ``world`` payloads on ``dst``, None elsewhere.
+    (all_gather rather than gather: it is the collective the north star names, and on the xGMI mesh its cost is
+    the same single hop; with 288 GB per GPU the padded receive buffer is not a concern.)"""
+    if world == 1 and not _collective_ready():
+        return [payload]
+    dev = payload.device
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([payload.numel()], dtype=torch.int64, device=dev))
+    sizes = [int(v) for v in sizes.tolist()]
+    cap = max(sizes)
+    if cap == 0:
+        return [payload.new_empty(0) for _ in range(world)] if rank == dst else None
+    send = payload.new_zeros(cap)
+    send[: payload.numel()] = payload
+    recv = payload.new_empty(world * cap)
+    dist.all_gather_into_tensor(recv, send)
+    if rank != dst:
+        return None
+    return [recv[r * cap: r * cap + sizes[r]] for r in range(world)]
+
+
+def run_scene_sharded(frame_counts, run_scene_fn, world: int, rank: int, on_scene_done=None, device=None):
+    """Incremental mode over a scan list (reference test_incremental.py:114-491, the ``for scan in scans`` loop).
+
+    ``run_scene_fn(scene_index)`` runs one scan's sequential per-frame loop (hint from TSDF(t-1) -> model -> fuse,
+    reference :172-372) on this rank and returns its fuser (anything with ``tsdf_fuser_pred.tsdf``) or None.  After
+    every round (the i-th scan of each rank) the finished TSDFs are gathered to rank 0, where
+    ``on_scene_done(scene_index, dict(tsdf_values, tsdf_weights, origin_f32, voxel_size))`` receives them in ascending
+    scan order of the round.  Returns this rank's list of scan indices."""
+    plan = shard_scenes(frame_counts, world)
+    rounds = max((len(p) for p in plan), default=0)
+    for i in range(rounds):
+        payload = None
+        if i < len(plan[rank]):
+            scene = plan[rank][i]
+            fuser = run_scene_fn(scene)
+            if fuser is not None:
+                t = fuser.tsdf_fuser_pred.tsdf
+                payload = pack_tsdf(t.tsdf_values, t.tsdf_weights, t.origin_f32, t.voxel_size, scene)
+        if payload is None:
+            payload = torch.empty(0, dtype=torch.uint8, device=device if device is not None else "cpu")
+        got = gather_variable(payload, world, dst=0, rank=rank)
+        if rank == 0 and on_scene_done is not None:
+            done = [unpack_tsdf(g) for g in got if g.numel()]
+            for d in sorted(done, key=lambda d: d["scene_index"]):
+                on_scene_done(d.pop("scene_index"), d)
+    return plan[rank]

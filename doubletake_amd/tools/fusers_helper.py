@@ -38,6 +38,29 @@ def _ply_vertices(path):
         return np.stack([arr[a].astype(np.float64) for a in "xyz"], 1)
 
 
+def _obj_vertices(path):
+    """Vertex positions of a Wavefront OBJ (3RScan ground-truth meshes are mesh.refined.v2.obj)."""
+    out = []
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            if line.startswith("v "):
+                out.append([float(x) for x in line.split()[1:4]])
+    return np.asarray(out, dtype=np.float64).reshape(-1, 3)
+
+
+def _mesh_vertices(path):
+    return _obj_vertices(path) if str(path).lower().endswith(".obj") else _ply_vertices(path)
+
+
+class SimpleMesh:
+    """vertices/faces holder returned by OurFuser.get_mesh (stand-in for trimesh.Trimesh, which is not installed)."""
+
+    def __init__(self, vertices, faces):
+        self.vertices = vertices
+        self.faces = faces
+        self.triangles = faces
+
+
 class DepthFuser:
     def __init__(self, gt_path="", fusion_resolution=0.04, max_fusion_depth=3.0, fuse_color=False):
         self.fusion_resolution = fusion_resolution
@@ -52,7 +75,7 @@ class OurFuser(DepthFuser):
         if bounds is not None:
             tsdf_pred = TSDF.from_bounds(bounds, voxel_size=fusion_resolution)
         elif gt_path is not None and gt_path != "":
-            tsdf_pred = TSDF.from_mesh(_Verts(_ply_vertices(gt_path)), voxel_size=fusion_resolution)
+            tsdf_pred = TSDF.from_mesh(_Verts(_mesh_vertices(gt_path)), voxel_size=fusion_resolution)
         else:
             b = {"xmin": -10.0, "xmax": 10.0, "ymin": -10.0, "ymax": 10.0, "zmin": -10.0, "zmax": 10.0}
             tsdf_pred = TSDF.from_bounds(b, voxel_size=fusion_resolution)
@@ -65,10 +88,13 @@ class OurFuser(DepthFuser):
             extended_neg_truncation=self.extended_neg_truncation)
 
     def export_mesh(self, path, export_single_mesh=True, trim_tsdf_using_confience=False):
+        """Reference :75-79.  Writes the GPU marching-cubes mesh of the active voxels; the PLY header carries a
+        comment saying so, because the reference's exported (scored) mesh comes from its CPU skimage path."""
         _, verts, faces = self.get_mesh_pytorch3d()
         from ..utils.formats import write_ply
 
-        write_ply(path, verts.cpu().numpy(), faces.cpu().numpy())
+        write_ply(path, verts.cpu().numpy(), faces.cpu().numpy(),
+                  comment="doubletake_amd: active-voxel GPU marching cubes (TSDF.to_mesh_pytorch3d), not TSDF.to_mesh")
 
     def save_tsdf(self, path):
         self.tsdf_fuser_pred.tsdf.save_tsdf(path)
@@ -78,8 +104,61 @@ class OurFuser(DepthFuser):
                                                      sampling_method=sampling_method)
 
     def get_mesh(self, export_single_mesh=True, convert_to_trimesh=True):
-        return self.tsdf_fuser_pred.tsdf.to_mesh(export_single_mesh=export_single_mesh)
+        """Reference :84-92 meshes the whole volume on the CPU with a scikit-image fork (out of scope)
+        and wraps it in a trimesh.  Here: the GPU marching-cubes mesh of the active voxels (to_mesh_pytorch3d) as a
+        small object with ``.vertices`` [V,3] / ``.faces`` [F,3] numpy arrays -- what the reference drivers read from
+        the trimesh.  Not vertex-for-vertex the skimage mesh (no unobserved-space faces, no single-mesh merge)."""
+        _, verts, faces = self.get_mesh_pytorch3d()
+        return SimpleMesh(verts.cpu().numpy(), faces.cpu().numpy().astype(np.int64))
 
     def get_mesh_pytorch3d(self, scale_to_world=True, min_bounds_3=None, max_bounds_3=None):
         return self.tsdf_fuser_pred.tsdf.to_mesh_pytorch3d(scale_to_world=scale_to_world, min_bounds_3=min_bounds_3,
                                                            max_bounds_3=max_bounds_3)
+
+
+#: where each dataset keeps the ground-truth mesh the fusion bounds come from
+#: (reference datasets/scannet_dataset.py:299-309, datasets/threer_scan_dataset.py:383-393, tools/fusers_helper.py:221-224)
+def gt_mesh_path(dataset, dataset_path, split, scan):
+    import os
+
+    if dataset == "scannet":
+        return os.path.join(dataset_path, "scans_test" if split == "test" else "scans", scan, f"{scan}_vh_clean_2.ply")
+    if dataset == "3rscan":
+        return os.path.join(dataset_path, "", scan, "mesh.refined.v2.obj")
+    if dataset == "7scenes":
+        return "/outputs/fused_gt/7scenes/default/meshes/0.04_8.0_ours/SCAN_NAME.ply".replace("SCAN_NAME", scan.replace("/", "_"))
+    return None
+
+
+def get_fuser(opts, scan):
+    """Factory of the drivers (reference tools/fusers_helper.py:214-243): reads ``opts.dataset``,
+    ``dataset_path``, ``split``, ``depth_fuser``, ``fusion_resolution``, ``fusion_max_depth``, ``fuse_color``,
+    ``extended_neg_truncation``.  "ours" -> the dense fp16 HIP fuser; "custom_open3d" -> the voxel-block fuser of
+    tools/sparse_fuser.py; "open3d" (stock Open3D ScalableTSDFVolume) is a third-party library path and not built."""
+    gt_path = gt_mesh_path(getattr(opts, "dataset", None), getattr(opts, "dataset_path", ""), getattr(opts, "split", "test"), scan)
+    if gt_path is not None:
+        import os
+
+        if not os.path.isfile(gt_path):
+            if opts.depth_fuser == "ours":
+                # the reference would crash inside trimesh.load here; the +-10 m default it uses for gt_path=None is
+                # the useful behaviour when the dataset ships no meshes (e.g. ScanNet test without *_vh_clean_2.ply)
+                print(f"WARNING: ground-truth mesh {gt_path} not found, using the default +-10 m fusion bounds.")
+            gt_path = None
+    if opts.depth_fuser == "ours":
+        if getattr(opts, "fuse_color", False):
+            print("WARNING: fusing color using 'ours' fuser is not supported, Color will not be fused.")
+        fuser = OurFuser(gt_path=gt_path, fusion_resolution=opts.fusion_resolution, max_fusion_depth=opts.fusion_max_depth,
+                         fuse_color=False, extended_neg_truncation=getattr(opts, "extended_neg_truncation", False))
+        fuser.tsdf_fuser_pred.tsdf.cuda()
+        return fuser
+    if opts.depth_fuser == "custom_open3d":
+        from .sparse_fuser import CustomOpen3dFuser
+
+        return CustomOpen3dFuser(gt_path=gt_path, fusion_resolution=opts.fusion_resolution,
+                                 max_fusion_depth=opts.fusion_max_depth, fuse_color=getattr(opts, "fuse_color", False),
+                                 extended_neg_truncation=getattr(opts, "extended_neg_truncation", False))
+    if opts.depth_fuser == "open3d":
+        raise NotImplementedError("depth_fuser='open3d' wraps Open3D's ScalableTSDFVolume (third-party, out of scope); "
+                                  "use 'ours' or 'custom_open3d'")
+    raise ValueError("Unrecognized fuser!")

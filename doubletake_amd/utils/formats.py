@@ -91,10 +91,11 @@ def read_scores_json(filepath):
 
 
 # ---- PLY ------------------------------------------------------------------------------------------
-def write_ply(path, verts, faces):
+def write_ply(path, verts, faces, comment=None):
     v = np.ascontiguousarray(np.asarray(verts, dtype="<f4").reshape(-1, 3))
     f = np.ascontiguousarray(np.asarray(faces, dtype="<i4").reshape(-1, 3))
-    header = (f"ply\nformat binary_little_endian 1.0\nelement vertex {len(v)}\nproperty float x\nproperty float y\n"
+    note = f"comment {comment}\n" if comment else ""
+    header = (f"ply\nformat binary_little_endian 1.0\n{note}element vertex {len(v)}\nproperty float x\nproperty float y\n"
               f"property float z\nelement face {len(f)}\nproperty list uchar int vertex_indices\nend_header\n")
     rec = np.empty(len(f), dtype=[("n", "u1"), ("idx", "<i4", 3)])
     rec["n"] = 3

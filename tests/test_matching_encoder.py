@@ -197,3 +197,30 @@ def test_model_matching_feats_and_cross_frame_cache():
     cache.capacity = 4
     cache.put("x", c_cur[0])
     assert len(cache) == 4 and "x" in cache
+
+
+@pytest.mark.gpu
+def test_feature_cache_is_keyed_by_scan_and_weights():
+    """Frame ids repeat across scans and entries die with the weights that produced them."""
+    import gpu_util as gu
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
+
+    model = DepthModelCVHint(64, 96, depth_decoder_name="skip", matching_num_depth_bins=8, model_num_views=3)
+    _fill(model.matching_model, 21)
+    model = model.to(gu.dev())
+    img = lambda s: torch.from_numpy(syn.hash_normalish((1, 3, 64, 96), s)).to(gu.dev())
+    src = lambda s: torch.from_numpy(syn.hash_normalish((1, 2, 3, 64, 96), s)).to(gu.dev())
+    ids = dict(cur_ids=["000012"], src_ids=[["000010"], ["000008"]])
+    a_cur, _ = model.compute_matching_feats(img(1), src(2), scan_ids="scene0707_00", **ids)
+    # same frame-id strings, different scan and different pixels: must NOT be served from the first scan's entries
+    b_cur, _ = model.compute_matching_feats(img(3), src(4), scan_ids="scene0708_00", **ids)
+    want, _ = model.compute_matching_feats(img(3), src(4))
+    assert (b_cur - want).abs().max() < 1e-4 and (b_cur - a_cur).abs().max() > 1e-2
+    cache = model.matching_feature_cache
+    assert len(cache) == 6
+    # a weight update invalidates everything
+    with torch.no_grad():
+        next(model.matching_model.parameters()).mul_(1.5)
+    c_cur, _ = model.compute_matching_feats(img(1), src(2), scan_ids="scene0707_00", **ids)
+    want, _ = model.compute_matching_feats(img(1), src(2))
+    assert len(cache) == 3 and (c_cur - want).abs().max() < 1e-4 and (c_cur - a_cur).abs().max() > 1e-3

@@ -1,16 +1,20 @@
-"""world_size-2 CPU (gloo) test of the keyframe-shard exchange: canonical order, payload integrity,
-replica determinism.  The GPU fuser is replaced by a recording callback (the collective logic is
-device independent)."""
+"""world_size-2 CPU (gloo) tests of the multi-GPU modes of doubletake_amd/parallel.py: the keyframe-shard exchange
+(canonical order, payload integrity, ragged schedules), the sharded two-pass loop (replicas bit-identical to a serial
+run, checked by integrating with the numpy TSDF oracle), and the scene-sharded incremental loop with the
+size-then-padded gather of finished TSDFs.  The collective logic is device independent; the HIP fuser is replaced by a
+recording callback or by the oracle."""
 import os
 import socket
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from doubletake_amd import parallel as par
+from doubletake_amd.utils import synthetic as syn
+
+BD = dict(xmin=-1.28, xmax=1.28, ymin=-1.12, ymax=1.12, zmin=0.0, zmax=2.24)
 
 
 def _free_port():
@@ -21,17 +25,28 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _init(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _spawn(fn, world, *args):
+    mp.spawn(fn, args=(world, _free_port(), *args), nprocs=world, join=True)
+
+
+# ---- per-step exchange ---------------------------------------------------------------------------
+def _exchange_worker(rank, world, port, out_dir):
+    _init(rank, world, port)
     h, w = 6, 8
     log = []
-    fuser = par.KeyframeShardFuser(torch.device("cpu"), world, rank, 2 * h, 2 * w,
-                                   fuse_fn=lambda d, K, T: log.append((d.clone(), K.clone(), T.clone())), pool=16)
+    fuser = par.KeyframeShardFuser(torch.device("cpu"), world, rank, (h, w),
+                                   fuse_fn=lambda d, K, T: log.append((d.clone(), K.clone(), T.clone())))
+    _, K, T = syn.tsdf_frames(16, h, w, seed=5, bounds=BD)
     for step in range(3):
+        g = step * world + rank
         depth = torch.full((1, 1, h, w), float(10 * step + rank + 1)) + torch.arange(w).float() * 0.01
-        n = fuser.exchange_and_fuse(depth, step)
+        n = fuser.exchange_and_fuse(depth, torch.from_numpy(K[g:g + 1]), torch.from_numpy(T[g:g + 1]))
         assert n == world
     torch.save(log, os.path.join(out_dir, f"log{rank}.pt"))
     dist.destroy_process_group()
@@ -39,9 +54,10 @@ def _worker(rank, world, port, out_dir):
 
 def test_exchange_two_ranks(tmp_path):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    _spawn(_exchange_worker, world, str(tmp_path))
     logs = [torch.load(os.path.join(tmp_path, f"log{r}.pt")) for r in range(world)]
     assert len(logs[0]) == len(logs[1]) == 3
+    _, K, T = syn.tsdf_frames(16, 6, 8, seed=5, bounds=BD)
     for step in range(3):
         d0, K0, T0 = logs[0][step]
         d1, K1, T1 = logs[1][step]
@@ -51,14 +67,9 @@ def test_exchange_two_ranks(tmp_path):
         for r in range(world):
             want = (torch.full((6, 8), float(10 * step + r + 1)) + torch.arange(8).float() * 0.01).half()
             assert torch.equal(d0[r, 0], want)
-    # the pool index follows the global frame id: step*world + rank
-    from doubletake_amd.utils import synthetic as syn
-
-    _, K, T = syn.tsdf_frames(16, 6, 8, seed=5, bounds=par.KeyframeShardFuser.BOUNDS)
-    for step in range(3):
-        for r in range(world):
-            np.testing.assert_array_equal(logs[0][step][1][r].numpy(), K[(step * world + r) % 16].astype(np.float16))
-            np.testing.assert_array_equal(logs[0][step][2][r].numpy(), T[(step * world + r) % 16].astype(np.float16))
+            # the caller's cameras travel with the depth (cast to half exactly as OurFuser.fuse_frames does)
+            np.testing.assert_array_equal(K0[r].numpy(), K[step * world + r].astype(np.float16))
+            np.testing.assert_array_equal(T0[r].numpy(), T[step * world + r].astype(np.float16))
 
 
 def test_pack_roundtrip_and_sharding():
@@ -70,3 +81,153 @@ def test_pack_roundtrip_and_sharding():
     shards = [par.shard_keyframes(11, 4, r) for r in range(4)]
     assert sorted(sum(shards, [])) == list(range(11))
     assert shards[1] == [1, 5, 9]
+
+
+def test_single_rank_needs_no_process_group():
+    log = []
+    f = par.KeyframeShardFuser(torch.device("cpu"), 1, 0, (4, 5), fuse_fn=lambda d, K, T: log.append(d), upsample_to=(8, 10))
+    d = torch.arange(20.0).view(1, 1, 4, 5)
+    assert f.exchange_and_fuse(d, torch.eye(4)[None], torch.eye(4)[None]) == 1
+    assert tuple(log[0].shape) == (1, 1, 8, 10) and torch.equal(log[0][0, 0, ::2, ::2], d[0, 0])
+    assert f.exchange_and_fuse(None, None, None) == 0
+
+
+# ---- sharded two-pass loop -----------------------------------------------------------------------------
+H, W = 24, 32
+NB = 5                      # keyframe batches of the "scan": sizes 2,2,2,2,1 (ragged tail, odd batch count)
+SIZES = [2, 2, 2, 2, 1]
+
+
+def _scan_frames():
+    depth, K, T = syn.tsdf_frames(sum(SIZES), H, W, seed=9, bounds=BD)
+    return (depth * np.float32(0.6)).astype(np.float32), K, T
+
+
+def _batch(i):
+    depth, K, T = _scan_frames()
+    s = sum(SIZES[:i])
+    sl = slice(s, s + SIZES[i])
+    return torch.from_numpy(depth[sl]), torch.from_numpy(K[sl]), torch.from_numpy(T[sl])
+
+
+class _OracleFuser:
+    """fuse_frames on the numpy TSDF oracle: lets a CPU test check replica bits."""
+
+    def __init__(self, voxel):
+        from oracle import tsdf_ref
+
+        self.ref = tsdf_ref
+        self.vol = tsdf_ref.TSDFVolume(BD, voxel)
+        self.order = []
+
+    def fuse_frames(self, d, K, T, color=None):
+        assert d.dtype == torch.float16 and K.dtype == torch.float16
+        for j in range(d.shape[0]):
+            self.ref.integrate(self.vol, d[j, 0].numpy(), K[j].numpy(), T[j].numpy(), max_depth=3.0)
+            self.order.append(float(d[j, 0, 0, 0]))
+
+
+def _two_pass_worker(rank, world, port, out_dir):
+    _init(rank, world, port)
+    hint = _OracleFuser(0.08)
+    final = _OracleFuser(0.08)
+    calls = {"first": [], "second": [], "between": 0}
+
+    def first(i):
+        calls["first"].append(i)
+        return _batch(i)
+
+    def between(f):
+        assert f is hint
+        calls["between"] += 1
+        return {"w": hint.vol.weights.copy()}
+
+    def second(i, state):
+        calls["second"].append(i)
+        assert state["w"].sum() > 0
+        d, K, T = _batch(i)
+        return d * 1.01, K, T
+
+    sf_hint = par.KeyframeShardFuser(torch.device("cpu"), world, rank, (H, W), fuser=hint)
+    sf_final = par.KeyframeShardFuser(torch.device("cpu"), world, rank, (H, W), fuser=final)
+    n1, n2 = par.run_two_pass(NB, lambda i: SIZES[i], first, second, sf_hint, sf_final, between_passes=between)
+    assert (n1, n2) == (sum(SIZES), sum(SIZES)) and calls["between"] == 1
+    assert calls["first"] == calls["second"] == par.shard_keyframes(NB, world, rank)
+    np.savez(os.path.join(out_dir, f"vol{rank}.npz"), hv=hint.vol.values, hw=hint.vol.weights, fv=final.vol.values,
+             fw=final.vol.weights, order=np.array(hint.order))
+    dist.destroy_process_group()
+
+
+def test_two_pass_replicas_equal_serial_run(tmp_path):
+    world = 2
+    _spawn(_two_pass_worker, world, str(tmp_path))
+    vols = [np.load(os.path.join(tmp_path, f"vol{r}.npz")) for r in range(world)]
+    # serial single-process run over the same batches
+    hint, final = _OracleFuser(0.08), _OracleFuser(0.08)
+    for i in range(NB):
+        d, K, T = _batch(i)
+        hint.fuse_frames(d.half(), K.half(), T.half())
+        final.fuse_frames((d * 1.01).half(), K.half(), T.half())
+    assert (hint.vol.weights > 0).sum() > 500
+    for v in vols:
+        np.testing.assert_array_equal(v["order"], np.array(hint.order))  # canonical = serial batch order
+        for got, want in ((v["hv"], hint.vol.values), (v["hw"], hint.vol.weights), (v["fv"], final.vol.values),
+                          (v["fw"], final.vol.weights)):
+            np.testing.assert_array_equal(got.view(np.uint16), want.view(np.uint16))  # bit-identical replicas
+
+
+# ---- scene-sharded incremental mode ------------------------------------------------------------------------
+SCENE_FRAMES = [40, 10, 25, 12, 5]   # 5 scans, 2 ranks -> LPT: rank0 [0, 4], rank1 [2, 3, 1]? checked below
+SCENE_DIMS = [(8, 8, 8), (16, 8, 8), (8, 16, 8), (8, 8, 24), (24, 8, 8)]
+
+
+class _FakeTsdf:
+    def __init__(self, scene):
+        g = torch.Generator().manual_seed(100 + scene)
+        self.tsdf_values = (torch.rand(SCENE_DIMS[scene], generator=g) * 2 - 1).half()
+        self.tsdf_weights = torch.rand(SCENE_DIMS[scene], generator=g).half()
+        self.origin_f32 = np.array([0.1 * scene, -1.37, 2.5e-3], dtype=np.float32)
+        self.voxel_size = 0.04 if scene % 2 else 0.02
+
+
+class _FakeFuser:
+    def __init__(self, scene):
+        self.tsdf_fuser_pred = type("F", (), {"tsdf": _FakeTsdf(scene)})()
+
+
+def _scene_worker(rank, world, port, out_dir):
+    _init(rank, world, port)
+    ran, got = [], {}
+    mine = par.run_scene_sharded(SCENE_FRAMES, lambda s: (ran.append(s), _FakeFuser(s))[1], world, rank,
+                                 on_scene_done=lambda s, d: got.__setitem__(s, d), device="cpu")
+    assert ran == mine
+    torch.save({"mine": mine, "got": got}, os.path.join(out_dir, f"scenes{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_scene_shard_and_tsdf_gather(tmp_path):
+    world = 2
+    plan = par.shard_scenes(SCENE_FRAMES, world)
+    assert sorted(sum(plan, [])) == list(range(5)) and plan[0][0] == 0 and plan[1][0] == 2
+    loads = [sum(SCENE_FRAMES[i] for i in p) for p in plan]
+    assert max(loads) <= 52                                   # 92 frames: LPT gives 45/47 or similar, never worse than 4/3 OPT
+    _spawn(_scene_worker, world, str(tmp_path))
+    res = [torch.load(os.path.join(tmp_path, f"scenes{r}.pt"), weights_only=False) for r in range(world)]
+    assert [r["mine"] for r in res] == plan
+    assert res[1]["got"] == {}                                # only rank 0 receives the volumes
+    got = res[0]["got"]
+    assert sorted(got) == list(range(5))
+    for s in range(5):
+        want = _FakeTsdf(s)
+        assert torch.equal(got[s]["tsdf_values"], want.tsdf_values) and torch.equal(got[s]["tsdf_weights"], want.tsdf_weights)
+        np.testing.assert_array_equal(got[s]["origin_f32"], want.origin_f32)  # fp32 placement survives bit for bit
+        assert got[s]["voxel_size"] == float(np.float32(want.voxel_size))
+
+
+def test_gather_variable_single_process():
+    p = torch.arange(5, dtype=torch.uint8)
+    out = par.gather_variable(p, 1)
+    assert len(out) == 1 and torch.equal(out[0], p)
+    buf = par.pack_tsdf(torch.ones(8, 8, 8).half(), torch.zeros(8, 8, 8).half(), [1.5, -2.25, 3.0], 0.04, 7)
+    d = par.unpack_tsdf(buf)
+    assert d["scene_index"] == 7 and d["tsdf_values"].shape == (8, 8, 8) and float(d["tsdf_values"].sum()) == 512.0
