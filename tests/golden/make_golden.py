@@ -256,6 +256,67 @@ def gen_volume_fullsize(ref, out):
     np.savez_compressed(os.path.join(out, "volume_fullsize_checksums.npz"), **res)
 
 
+#: whole-model cases at the BASELINE.json shapes (SURVEY.md section 8 cfg table): name -> (b, K, h, w, D, seed, decoder)
+MODEL_FULLSIZE_CASES = {
+    "cfg2_small": (1, 7, 120, 160, 64, 201, "skip"),      # configs[1]: DoubleTake-small 640x480
+    "cfg2_full": (1, 7, 120, 160, 64, 202, "unet_pp"),    # the full model at the same frame size
+    "cfg3_full_b8": (8, 7, 96, 128, 64, 203, "unet_pp"),  # configs[2]: full model, 512x384, batch 8
+    "cfg3_small_b8": (8, 7, 96, 128, 64, 204, "skip"),
+    "cfg4_small": (1, 7, 96, 128, 64, 205, "skip"),       # configs[3]: incremental mode is batch 1 at 512x384
+    "cfg5_full_d96": (2, 7, 128, 96, 96, 206, "unet_pp"),  # configs[4]: portrait 384x512, 96 planes (CVEncoder in-ch = 96)
+    "cfg5_small_d96": (2, 7, 128, 96, 96, 207, "skip"),
+}
+MODEL_ENC_WIDTHS = {"skip": [64, 64, 128, 256, 512], "unet_pp": [24, 48, 64, 160, 256]}
+
+
+def gen_model_fullsize(ref, out):
+    """Whole hot path at full size through the reference's own modules: FeatureMeshHintVolumeManager (loop) ->
+    CVEncoder -> SkipDecoderRegression | DepthDecoderPP -> exp, i.e. doubletake_model.py:379-418 without the image
+    encoders.  Stores sum / abs-sum / min / max / 256 probes of every output (tests/test_model_fullsize_gpu.py)."""
+    import torch
+    from doubletake_amd.utils import synthetic as syn
+
+    N, NF = ref["networks"], ref["networks_fast"]
+    res = {}
+    for name, (b, k, h, w, D, seed, dec_name) in MODEL_FULLSIZE_CASES.items():
+        inp = syn.volume_inputs(b, k, h, w, 16, seed)
+        ti = {n: t(v) for n, v in inp.items()}
+        hint = {n: ti[n] for n in ("depth_hint_b1hw", "depth_hint_mask_b1hw", "sampled_weights_b1hw")}
+        common = {n: ti[n] for n in ("cur_feats", "src_feats", "src_extrinsics", "src_poses", "src_Ks", "cur_invK", "min_depth", "max_depth")}
+        enc = MODEL_ENC_WIDTHS[dec_name]
+        pyr = [t(f) for f in syn.prior_pyramid(b, enc, 2 * h, 2 * w, seed + 50)]
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            hv = ref["mesh_hint_volume"].FeatureMeshHintVolumeManager(
+                h, w, num_depth_bins=D, mlp_channels=[202, 128, 128, 1], matching_dim_size=16, num_source_views=k)
+            set_formula_weights(hv.mlp, seed + 1)
+            set_formula_weights(hv.hint_mlp, seed + 2)
+            vol, low, _, mask = hv(**common, cv_depth_hint_dict={n: v.clone() for n, v in hint.items()}, return_mask=True)
+            cve = N.CVEncoder(num_ch_cv=D, num_ch_enc=enc[1:], num_ch_outs=[64, 128, 256, 384])
+            set_formula_weights(cve, seed + 3)
+            cv_out = cve(vol, pyr[1:])
+            if dec_name == "skip":
+                dec = NF.SkipDecoderRegression([enc[0]] + [64, 128, 256, 384])
+                set_formula_weights(dec, seed + 4)
+            else:
+                dec = N.DepthDecoderPP([enc[0]] + [64, 128, 256, 384])
+                set_formula_weights(dec, seed + 4, scale_mult=0.7)
+            dout = dec([pyr[0]] + cv_out)
+        outs = {"volume": vol, "lowest_cost": low, "mask_sum": mask.float().sum(1) if mask.dim() == 4 else mask.float()}
+        for i, o in enumerate(cv_out):
+            outs[f"cv_feat{i}"] = o
+        for kk, v in dout.items():
+            if kk.startswith("log_depth"):
+                outs[kk] = v
+                outs[kk.replace("log_", "")] = torch.exp(v)
+        for on, ov in outs.items():
+            for kk, vv in checksum(ov.numpy(), nprobe=256).items():
+                res[f"{name}|{on}|{kk}"] = vv
+        res[f"{name}|meta"] = np.array([b, k, h, w, D, seed], dtype=np.int64)
+        print(f"model_fullsize {name}: depth_s0 range {float(outs['depth_pred_s0_b1hw'].min()):.3f} .. "
+              f"{float(outs['depth_pred_s0_b1hw'].max()):.3f}", flush=True)
+    np.savez_compressed(os.path.join(out, "model_fullsize_checksums.npz"), **res)
+
+
 def gen_networks(ref, out):
     import torch
     from doubletake_amd.utils import synthetic as syn
@@ -434,7 +495,7 @@ def gen_formats(ref, out):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"volume", "fullsize", "networks", "tsdf", "formats"}
+    which = set(sys.argv[1:]) or {"volume", "fullsize", "networks", "model_fullsize", "tsdf", "formats"}
     ref = import_reference()
     if "volume" in which:
         gen_volume(ref, OUT)
@@ -442,6 +503,8 @@ def main():
         gen_volume_fullsize(ref, OUT)
     if "networks" in which:
         gen_networks(ref, OUT)
+    if "model_fullsize" in which:
+        gen_model_fullsize(ref, OUT)
     if "tsdf" in which:
         gen_tsdf(ref, OUT)
     if "formats" in which:

@@ -1,0 +1,64 @@
+"""GPU: the keyframe-shard exchange over a real RCCL process group (world size 1 -- the box has one GPU) with the real HIP
+fuser: init, all_gather_into_tensor of the packed fp16 update on the device, unpack, replica integrate.  The replica must
+be bit-identical to fusing the same frames serially without any collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from doubletake_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+BD = dict(xmin=-1.28, xmax=1.28, ymin=-1.12, ymax=1.12, zmin=0.0, zmax=2.24)
+
+
+def test_world1_rccl_exchange_equals_serial_fuse():
+    import torch.distributed as dist
+
+    import gpu_util as gu
+    from doubletake_amd import parallel as par
+    from doubletake_amd.tools.fusers_helper import OurFuser
+
+    dev = gu.dev()
+    torch.cuda.set_device(dev)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    s.close()
+    os.environ.pop("NCCL_DEBUG", None)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        H, W = 120, 160
+        depth, K, T = syn.tsdf_frames(6, H, W, seed=3, bounds=BD)
+        depth = depth * np.float32(0.6)
+        d, k, t = (torch.from_numpy(a).to(dev) for a in (depth, K, T))
+        serial = OurFuser(None, 0.04, 3.0, bounds=BD)
+        replica = OurFuser(None, 0.04, 3.0, bounds=BD)
+        sf = par.KeyframeShardFuser(dev, 1, 0, (H, W), fuser=replica, force_collective=True)
+        # batches of 2, 2, 1, 1 frames: the ragged path (rows > count) goes through the collective as well
+        sizes = [2, 2, 1, 1]
+        starts = np.cumsum([0] + sizes)
+        n = par.run_sharded_pass(len(sizes), lambda i: sizes[i],
+                                 lambda i: (d[starts[i]:starts[i + 1]], k[starts[i]:starts[i + 1]], t[starts[i]:starts[i + 1]]), sf)
+        for i in range(len(sizes)):
+            sl = slice(starts[i], starts[i + 1])
+            serial.fuse_frames(d[sl], k[sl], t[sl], None)
+        torch.cuda.synchronize()
+        assert n == 6 and sf.frames_fused == 6 and sf._all is not None and sf._all.is_cuda
+        a, b = serial.tsdf_fuser_pred.tsdf, replica.tsdf_fuser_pred.tsdf
+        assert (a.tsdf_weights > 0).sum().item() > 10000
+        assert torch.equal(a.tsdf_values.view(torch.int16), b.tsdf_values.view(torch.int16))
+        assert torch.equal(a.tsdf_weights.view(torch.int16), b.tsdf_weights.view(torch.int16))
+        assert torch.equal(a.voxel_bitmap, b.voxel_bitmap)
+        # variable-size TSDF gather (scene-shard mode) over the same group
+        got = {}
+        par.run_scene_sharded([5], lambda s_: replica, 1, 0, on_scene_done=lambda s_, dd: got.__setitem__(s_, dd), device=dev)
+        assert torch.equal(got[0]["tsdf_values"], b.tsdf_values) and torch.equal(got[0]["tsdf_weights"], b.tsdf_weights)
+        np.testing.assert_array_equal(got[0]["origin_f32"], b.origin_f32)
+    finally:
+        dist.destroy_process_group()
