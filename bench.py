@@ -157,41 +157,59 @@ def cpu_baseline(inp, pyr, model, threads="8,all", batched=False):
 
 
 def dot_volume_roofline(device, t, launches=30):
-    """North-star side figure: the plain dot-product warp+match kernel (cv_dot_kernel, the volume of
-    CostVolumeManager) against the HBM roofline, on the same features.  Run AFTER the timed region;
-    HIP events bracket the kernel launch only.  Algorithmic bytes = inputs read once + volume written
-    once; gather bytes = what the bilinear taps really pull through L1."""
+    """North-star side figure: the plain dot-product warp+match kernel (cv_dot_lds_kernel, the volume of
+    CostVolumeManager) against the HBM roofline.  Run AFTER the timed region; HIP events bracket the kernel
+    launch only.  Algorithmic bytes = inputs read once + volume written once; tap bytes = what
+    the bilinear taps read (from LDS in the staged kernel, through L1 in the direct one).  Reported at B=1 on the
+    bench frame (cfg2) and at B=8 / 512x384 (cfg3); "direct" = the same kernel sampling from global memory."""
     import torch
     from doubletake_amd.modules import cost_volume as cvmod
+    from doubletake_amd.utils import synthetic as syn
+
+    k, D, c = CFG["num_src"], CFG["planes"], 16
+
+    def measure(tt, b, h, w, impl):
+        m = cvmod.CostVolumeManager(h, w, num_depth_bins=D).to(device)
+        evs = []
+
+        def hook(tag):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(device))
+            evs.append(ev)
+
+        call = lambda: m(tt["cur_feats"], tt["src_feats"], tt["src_extrinsics"], tt["src_poses"], tt["src_Ks"], tt["cur_invK"],
+                         tt["min_depth"], tt["max_depth"])
+        cvmod.CostVolumeManager._dot_impl = impl
+        try:
+            for _ in range(5):
+                call()
+            cvmod.CostVolumeManager._dot_event_hook = staticmethod(hook)
+            for _ in range(launches):
+                call()
+            torch.cuda.synchronize(device)
+        finally:
+            cvmod.CostVolumeManager._dot_event_hook = None
+            cvmod.CostVolumeManager._dot_impl = "lds"
+        ms = float(np.mean([evs[i].elapsed_time(evs[i + 1]) for i in range(0, len(evs), 2)]))
+        algo = 4.0 * b * h * w * (c * (k + 1) + D)
+        taps = 4.0 * b * h * w * D * k * 4 * c
+        return {"avg_launch_ms": ms, "achieved": algo / (ms * 1e-3) / 1e9, "frac": algo / (ms * 1e-3) / 1e9 / 8000.0,
+                "algorithmic_bytes_per_launch": algo, "bilinear_tap_bytes_per_launch": taps, "tap_GBps": taps / (ms * 1e-3) / 1e9}
 
     h, w = CFG["image_h"] // 4, CFG["image_w"] // 4
-    b, k, D, c = CFG["batch"], CFG["num_src"], CFG["planes"], 16
-    m = cvmod.CostVolumeManager(h, w, num_depth_bins=D).to(device)
-    evs = []
-
-    def hook(tag):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(torch.cuda.current_stream(device))
-        evs.append(ev)
-
-    call = lambda: m(t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"], t["src_Ks"], t["cur_invK"],
-                     t["min_depth"], t["max_depth"])
-    for _ in range(5):
-        call()
-    cvmod.CostVolumeManager._dot_event_hook = staticmethod(hook)
-    for _ in range(launches):
-        call()
-    torch.cuda.synchronize(device)
-    cvmod.CostVolumeManager._dot_event_hook = None
-    ms = float(np.mean([evs[i].elapsed_time(evs[i + 1]) for i in range(0, len(evs), 2)]))
-    algo = 4.0 * b * h * w * (c * (k + 1) + D)
-    gather = 4.0 * b * h * w * D * k * 4 * c
+    main = measure(t, CFG["batch"], h, w, "lds")
+    direct = measure(t, CFG["batch"], h, w, "direct")
+    t8 = {n: torch.from_numpy(v).to(device) for n, v in syn.volume_inputs(8, k, 96, 128, 16, 303).items()}
+    b8 = measure(t8, 8, 96, 128, "lds")
     return {
-        "kernel": "cv_dot_kernel (CostVolumeManager: warp + dot-product match, not on the DoubleTake path)",
-        "bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-        "frac": algo / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-        "algorithmic_bytes_per_launch": algo, "bilinear_gather_bytes_per_launch": gather,
-        "gather_GBps": gather / (ms * 1e-3) / 1e9, "avg_launch_ms": ms,
+        "kernel": "cv_dot_lds_kernel (CostVolumeManager: warp + dot-product match with LDS-staged source footprints; "
+                  "not on the DoubleTake path)",
+        "bound": "hbm", "achieved": main["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": main["frac"], "traffic": None,
+        "algorithmic_bytes_per_launch": main["algorithmic_bytes_per_launch"],
+        "bilinear_tap_bytes_per_launch": main["bilinear_tap_bytes_per_launch"], "tap_GBps": main["tap_GBps"],
+        "avg_launch_ms": main["avg_launch_ms"],
+        "direct_global_taps": {kk: direct[kk] for kk in ("avg_launch_ms", "achieved", "frac", "tap_GBps")},
+        "batch8_512x384": {kk: b8[kk] for kk in ("avg_launch_ms", "achieved", "frac", "algorithmic_bytes_per_launch", "tap_GBps")},
     }
 
 

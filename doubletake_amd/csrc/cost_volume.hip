@@ -101,62 +101,7 @@ __global__ __launch_bounds__(256) void cv_warp_kernel(const float* __restrict__ 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// dot-product volume.  One thread per pixel of a 32x8 tile, PC planes per block.
-// Source features are NHWC so one bilinear tap = C contiguous floats (float4 loads).
-// ------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(256) void cv_dot_kernel(const float* __restrict__ cur_bchw,
-                                                     const float* __restrict__ src_bkhwc,
-                                                     const float* __restrict__ params,
-                                                     float* __restrict__ vol, int K, int h, int w, int D,
-                                                     int planes_per_block) {
-  const int b = blockIdx.z;
-  const int tiles_x = (w + 31) / 32;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int x = tx * 32 + (threadIdx.x & 31), y = ty * 8 + (threadIdx.x >> 5);
-  const bool live = (x < w) && (y < h);
-  const int xc = min(x, w - 1), yc = min(y, h - 1);
-  const float* p = params + (size_t)b * cv_params_floats(D, K);
-  const size_t hw = (size_t)h * w;
-
-  float cur[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) cur[c] = cur_bchw[((size_t)b * C + c) * hw + (size_t)yc * w + xc];
-  float rx, ry, rz;
-  pixel_ray(p + kCvInvK, xc, yc, rx, ry, rz);
-  const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
-
-  const int d0 = blockIdx.y * planes_per_block;
-  const int d1 = min(d0 + planes_per_block, D);
-  for (int d = d0; d < d1; ++d) {
-    const float depth = p[kCvPlanes + d];
-    const float X = depth * rx, Y = depth * ry, Z = depth * rz;
-    float total = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float* vp = p + cv_view_off(D, k);
-      const ViewProj q = project_view(vp, X, Y, Z);
-      const Taps t = bilinear_taps(q.u, q.v, h, w, inv_w, inv_h);
-      const float* base = src_bkhwc + ((size_t)b * K + k) * hw * C;
-      const float4* p00 = reinterpret_cast<const float4*>(base + ((size_t)t.y0 * w + t.x0) * C);
-      const float4* p01 = reinterpret_cast<const float4*>(base + ((size_t)t.y0 * w + t.x1) * C);
-      const float4* p10 = reinterpret_cast<const float4*>(base + ((size_t)t.y1 * w + t.x0) * C);
-      const float4* p11 = reinterpret_cast<const float4*>(base + ((size_t)t.y1 * w + t.x1) * C);
-      float dot = 0.f;
-#pragma unroll
-      for (int c4 = 0; c4 < C / 4; ++c4) {
-        const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
-        const float f0 = a.x * t.w00 + bq.x * t.w01 + cq.x * t.w10 + dq.x * t.w11;
-        const float f1 = a.y * t.w00 + bq.y * t.w01 + cq.y * t.w10 + dq.y * t.w11;
-        const float f2 = a.z * t.w00 + bq.z * t.w01 + cq.z * t.w10 + dq.z * t.w11;
-        const float f3 = a.w * t.w00 + bq.w * t.w01 + cq.w * t.w10 + dq.w * t.w11;
-        dot += f0 * cur[c4 * 4 + 0] + f1 * cur[c4 * 4 + 1] + f2 * cur[c4 * 4 + 2] + f3 * cur[c4 * 4 + 3];
-      }
-      total += (q.z > 0.f) ? dot : 0.f;
-    }
-    if (live) vol[((size_t)b * D + d) * hw + (size_t)y * w + x] = total;
-  }
-}
+// (the dot-product volume lives in cv_dot_lds.hip)
 
 // ------------------------------------------------------------------------------------------
 // simple MLP / hint volume: one thread per (pixel, plane); everything in plain fp32 loops.
@@ -384,21 +329,6 @@ int dt_cv_warp_f32(const float* src_bkchw, const float* params, const float* dep
   hipLaunchKernelGGL(cv_warp_kernel, grid, dim3(256), 0, to_stream(s), src_bkchw, params, depth_bhw, num_src, channels, h, w,
                      num_planes, world_points_B4N, depths_bkhw, warped_bkchw, mask_bkhw);
   return check_launch("dt_cv_warp_f32");
-}
-
-int dt_cv_dot_f32(const float* cur, const float* src, const float* params, float* vol, int batch, int num_src,
-                  int channels, int h, int w, int num_planes, dt_stream_t s) {
-  DT_REQUIRE(batch > 0 && num_src > 0 && h > 0 && w > 0 && num_planes > 0, "dt_cv_dot_f32: bad extents");
-  DT_REQUIRE(channels == 16, "dt_cv_dot_f32: channels=%d unsupported (matching_feature_dims must be 16)", channels);
-  DT_REQUIRE(cur && src && params && vol, "dt_cv_dot_f32: null pointer");
-  const int tiles = ((w + 31) / 32) * ((h + 7) / 8);
-  // enough blocks to fill 256 CUs: split planes until >= ~1024 blocks or 4 planes per block
-  int ppb = num_planes;
-  while (ppb > 4 && (long)tiles * batch * ((num_planes + ppb - 1) / ppb) < 1024) ppb = (ppb + 1) / 2;
-  dim3 grid(tiles, (num_planes + ppb - 1) / ppb, batch);
-  hipLaunchKernelGGL(cv_dot_kernel<16>, grid, dim3(256), 0, to_stream(s), cur, src, params, vol, num_src, h, w,
-                     num_planes, ppb);
-  return check_launch("dt_cv_dot_f32");
 }
 
 int dt_cv_mlp_hint_simple_f32(const float* cur, const float* src, const float* params, const float* W1,

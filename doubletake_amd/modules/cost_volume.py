@@ -60,6 +60,8 @@ class CostVolumeManager(nn.Module):
     channels_last_output = True
     #: optional callable(tag) invoked right before / after dt_cv_dot_f32 (bench.py: HIP events)
     _dot_event_hook = None
+    #: "lds" (product path) | "direct" | "stats" -- see forward()
+    _dot_impl = "lds"
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, matching_dim_size=None,
                  num_source_views=None):
@@ -226,8 +228,19 @@ class CostVolumeManager(nn.Module):
         hook = CostVolumeManager._dot_event_hook
         if hook is not None:
             hook("dot_begin")
-        _abi.check(L.dt_cv_dot_f32(_abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(vol), b, k, c, h, w, D,
-                                   stream), "dt_cv_dot_f32")
+        impl = CostVolumeManager._dot_impl
+        if impl == "lds":      # source footprint of each pixel tile staged in LDS (csrc/cv_dot_lds.hip)
+            _abi.check(L.dt_cv_dot_f32(_abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(vol), b, k, c, h, w, D,
+                                       stream), "dt_cv_dot_f32")
+        elif impl == "direct":  # every tap from global memory: same expressions, bit-identical (tests, ablation)
+            _abi.check(L.dt_cv_dot_direct_f32(_abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(vol), b, k, c, h,
+                                              w, D, stream), "dt_cv_dot_direct_f32")
+        elif impl == "stats":
+            self.last_dot_stats = torch.zeros(4, dtype=torch.int32, device=cur.device)
+            _abi.check(L.dt_cv_dot_stats_f32(_abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(vol), b, k, c, h,
+                                             w, D, _abi.ptr(self.last_dot_stats), stream), "dt_cv_dot_stats_f32")
+        else:
+            raise ValueError(impl)
         if hook is not None:
             hook("dot_end")
         low = self._lowest(L, stream, vol, params, False, dims)

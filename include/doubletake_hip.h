@@ -67,6 +67,17 @@ int dt_cv_warp_f32(const float* src_bkchw, const float* params, const float* dep
 int dt_cv_dot_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc, const float* params,
                   float* volume_bdhw, int batch, int num_src, int channels, int h, int w,
                   int num_planes, dt_stream_t s);
+/* dt_cv_dot_f32 stages each source view's footprint of a pixel tile in LDS (csrc/cv_dot_lds.hip).  Two companions of
+ * the same kernel, for parity tests and ablations: ..._direct_ samples every tap straight from global memory (same
+ * expressions in the same order: bit-identical volume); ..._stats_ additionally counts, in stats4[0..3] (device ints,
+ * zeroed by the caller), (tile, plane-range, view) units that were staged / took the direct path / saw nothing of the
+ * view, and individual taps that missed their staged box (expected 0). */
+int dt_cv_dot_direct_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc, const float* params,
+                         float* volume_bdhw, int batch, int num_src, int channels, int h, int w,
+                         int num_planes, dt_stream_t s);
+int dt_cv_dot_stats_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc, const float* params,
+                        float* volume_bdhw, int batch, int num_src, int channels, int h, int w,
+                        int num_planes, int* stats4, dt_stream_t s);
 
 /* replaces: FeatureVolumeManager.build_cost_volume (modules/feature_volume.py:81-356) and
  * FeatureMeshHintVolumeManager.build_cost_volume (modules/mesh_hint_volume.py:84-393; Fast
