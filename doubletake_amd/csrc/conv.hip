@@ -976,7 +976,9 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
   // few output blocks (the 60x80 level and below): split K over two groups of four waves
   static const int force_split = [] { const char* e = getenv("DT_WINO_KSPLIT"); return e ? atoi(e) : 0; }();
   const int ksplit = force_split ? force_split : ((blocks < 256 && a.groups >= 8) ? 2 : 1);
-  if (ksplit == 2)
+  if (ksplit == 4)
+    hipLaunchKernelGGL(conv_wino_kernel<4>, dim3((unsigned)blocks), dim3(1024), 0, to_stream(s), a);
+  else if (ksplit == 2)
     hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)blocks), dim3(512), 0, to_stream(s), a);
   else
     hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, to_stream(s), a);

@@ -30,6 +30,12 @@ LAYERS_ALL = [
 ]
 
 
+if os.environ.get("DT_LAYER_SWEEP"):
+    # fixed cost vs per-K cost of one launch: same output, growing input channels
+    LAYERS_ALL = ([(f"sweep 3x3 {c}->64 120x160", c, 64, 3, 1, 120, 160) for c in (8, 16, 32, 64, 128, 256)] +
+                  [(f"sweep 3x3 {c}->128 60x80", c, 128, 3, 1, 60, 80) for c in (8, 32, 128, 256)] +
+                  [(f"sweep 3x3 {c}->256 30x40", c, 256, 3, 1, 30, 40) for c in (16, 64, 256, 512)] +
+                  [(f"sweep 3x3 {c}->384 15x20", c, 384, 3, 1, 15, 20) for c in (16, 128, 384, 896)])
 LAYERS = [l for l in LAYERS_ALL if not os.environ.get('DT_LAYER_FILTER') or any(f in l[0] for f in os.environ['DT_LAYER_FILTER'].split(','))]
 
 

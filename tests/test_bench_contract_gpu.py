@@ -31,3 +31,59 @@ def test_bench_json_contract():
     assert rf["traffic"] is None or rf["traffic"] > 1e6
     dot = d["roofline_warp_match_dot"]
     assert dot["bound"] == "hbm" and dot["unit"] == "GB/s" and dot["peak"] == 8000.0
+
+
+def test_two_stream_frame_pipelining_is_bit_identical():
+    """bench.py --streams 2 runs consecutive keyframes on alternating HIP streams with only the TSDF integrations
+    chained by events.  Same frames, same order: depth maps and the fused volume must not change by a bit."""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import gpu_util as gu
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
+    from doubletake_amd.tools.fusers_helper import OurFuser
+    from doubletake_amd.utils import synthetic as syn
+
+    dev = gu.dev()
+    h, w, k, D = 48, 64, 3, 16
+    model = DepthModelCVHint(4 * h, 4 * w, depth_decoder_name="skip", matching_num_depth_bins=D, model_num_views=k + 1,
+                             matching_encoder_type=None)
+    gu.set_formula_weights(model, 5)
+    model = model.to(dev)
+    bd = dict(xmin=-2.0, xmax=2.0, ymin=-2.0, ymax=2.0, zmin=0.0, zmax=2.4)
+    _, K, T = syn.tsdf_frames(6, 2 * h, 2 * w, seed=2, bounds=bd)
+    Kt, Tt = torch.from_numpy(K).to(dev), torch.from_numpy(T).to(dev)
+    frames = []
+    for f in range(6):
+        t = gu.to_dev(syn.volume_inputs(1, k, h, w, 16, 30 + f))
+        pyr = [torch.from_numpy(p).to(dev) for p in syn.prior_pyramid(1, [64, 64, 128, 256, 512], 2 * h, 2 * w, 40 + f)]
+        frames.append((t, pyr))
+
+    def run(nstreams):
+        fuser = OurFuser(None, 0.04, 3.0, bounds=bd)
+        streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        done, outs = None, []
+        for f, (t, pyr) in enumerate(frames):
+            with torch.cuda.stream(streams[f % nstreams]):
+                out = model.forward_from_features(pyr, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"],
+                                                  t["src_Ks"], t["cur_invK"], gu.hint_dict(t), return_mask=True)
+                cur = torch.cuda.current_stream(dev)
+                if done is not None:
+                    cur.wait_event(done)
+                fuser.fuse_frames(out["depth_pred_s0_b1hw"].clamp(0.8, 2.0), Kt[f:f + 1], Tt[f:f + 1], None)
+                done = torch.cuda.Event()
+                done.record(cur)
+                outs.append(out["depth_pred_s0_b1hw"])
+        torch.cuda.synchronize(dev)
+        t = fuser.tsdf_fuser_pred.tsdf
+        return [o.clone() for o in outs], t.tsdf_values.clone(), t.tsdf_weights.clone()
+
+    d1, v1, w1 = run(1)
+    d2, v2, w2 = run(2)
+    for a, b in zip(d1, d2):
+        assert torch.equal(a, b)
+    assert (w1 > 0).sum().item() > 1000
+    assert torch.equal(v1.view(torch.int16), v2.view(torch.int16)) and torch.equal(w1.view(torch.int16), w2.view(torch.int16))
