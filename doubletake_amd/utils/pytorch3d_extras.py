@@ -75,6 +75,16 @@ def marching_cubes_raw(values_f16: torch.Tensor, bitmap: torch.Tensor, isolevel:
     return verts, faces, ids
 
 
+def merge_by_edge_id(soup_verts: torch.Tensor, soup_faces: torch.Tensor, edge_ids: torch.Tensor):
+    """Triangle soup -> indexed mesh.  Every vertex of the soup lies on a lattice edge and carries that edge's int64 id,
+    so vertices with equal ids are the same point: keep one per id (ids ascending) and re-index the faces.
+    (What the reference does with torch.unique for its CUDA path, utils/pytorch3d_extras.py:90-96.)"""
+    ids_sorted, soup_to_merged = torch.unique(edge_ids, return_inverse=True)
+    merged = soup_verts.new_zeros((ids_sorted.numel(), soup_verts.shape[1]))
+    merged[soup_to_merged] = soup_verts  # duplicates write identical values
+    return merged, soup_to_merged[soup_faces]
+
+
 def marching_cubes(
     vol_batch: torch.Tensor,
     active_voxels: torch.Tensor,
@@ -84,29 +94,22 @@ def marching_cubes(
     max_bounds: Optional[torch.Tensor] = None,
 ) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
     """Reference signature (utils/pytorch3d_extras.py:39-107).  ``active_voxels`` is either the
-    [N,3] key list the reference passes or an int32 bitmap (see keys_to_bitmap)."""
-    batched_verts, batched_faces = [], []
-    D, H, W = vol_batch.shape[1:]
-    for i in range(len(vol_batch)):
-        vol = vol_batch[i]
-        thresh = ((vol.max() + vol.min()) / 2).item() if isolevel is None else isolevel
-        bitmap = active_voxels if active_voxels.dim() == 1 else keys_to_bitmap(active_voxels, (D, H, W))
-        verts, faces, ids = marching_cubes_raw(vol, bitmap, thresh, min_bounds, max_bounds)
-        if len(faces) > 0 and len(verts) > 0:
-            if return_local_coords:
-                scale = (vol.new_tensor([W, H, D], dtype=torch.float32)[None] - 1) * 0.5
-                verts = verts / scale - 1.0
-            # dedup by edge id, exactly as the reference does for its CUDA path (:90-96)
-            unique_ids, inverse_idx = torch.unique(ids, return_inverse=True)
-            verts_ = verts.new_zeros(unique_ids.shape[0], 3)
-            verts_[inverse_idx] = verts
-            verts = verts_
-            faces = inverse_idx[faces]
-            verts = verts[:, [2, 1, 0]]
-            faces = faces.flip(1)
-            batched_verts.append(verts)
-            batched_faces.append(faces)
-        else:
-            batched_verts.append([])
-            batched_faces.append([])
-    return batched_verts, batched_faces
+    [N,3] key list the reference passes or an int32 bitmap (see keys_to_bitmap).  Returns per batch element the
+    merged vertices in (x, y, z) order and faces with reversed winding, or empty lists for an empty surface."""
+    out_verts, out_faces = [], []
+    nx, ny, nz = vol_batch.shape[1:]
+    for vol in vol_batch:
+        level = float((vol.max() + vol.min()) / 2) if isolevel is None else isolevel
+        bitmap = active_voxels if active_voxels.dim() == 1 else keys_to_bitmap(active_voxels, (nx, ny, nz))
+        soup, tris, ids = marching_cubes_raw(vol, bitmap, level, min_bounds, max_bounds)
+        if soup.shape[0] == 0 or tris.shape[0] == 0:
+            out_verts.append([])
+            out_faces.append([])
+            continue
+        if return_local_coords:  # [-1, 1] over the (k, j, i) lattice extents
+            half_extent = (vol.new_tensor([nz, ny, nx], dtype=torch.float32) - 1) * 0.5
+            soup = soup / half_extent[None] - 1.0
+        merged, tris = merge_by_edge_id(soup, tris, ids)
+        out_verts.append(merged.flip(1))   # kernel order (k, j, i) -> (i, j, k) = world (x, y, z)
+        out_faces.append(tris.flip(1))     # the axis flip mirrors the mesh: reverse the winding with it
+    return out_verts, out_faces

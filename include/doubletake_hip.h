@@ -313,6 +313,36 @@ int dt_hint_from_depth_f32(const float* depth_hw, const uint16_t* weights_vol_f1
                            float* hint_hw, float* mask_hw, uint8_t* mask_b_hw,
                            float* sampled_weights_hw, dt_stream_t s);
 
+/* ---- voxel-block (sparse) fp32 TSDF ------------------------------------------
+ * replaces: CustomOpen3dFuser (tools/fusers_helper.py:263-511) over Open3D's VoxelBlockGrid (open3d==0.18.0,
+ * third party: algorithm restated, parity unpinned).  The grid is seven caller-owned device buffers:
+ *   dir      int32 [nb^3]      block directory over block coordinates [-nb/2, nb/2)^3, -1 = unallocated (init -1)
+ *   touch    uint8 [nb^3]      per-frame marks (init 0)
+ *   keys     int32 [cap*3]     block coordinates per slot
+ *   tsdf, weight fp32 [cap*4096]  16^3-voxel tiles, index (lx*16 + ly)*16 + lz (init 0)
+ *   count2   int32 [2]         [0] allocated slots, [1] blocks that could not be placed (capacity / directory extent)
+ * dt_sparse_integrate_f32 = compute_unique_block_coordinates + activate (:326-336) + update_tsdf_for_voxels (:369-441)
+ * for ONE depth map [h,w] fp32 (device); K44 / cam_T_world44 are HOST pointers (16 floats, row-major).
+ * trunc_voxels: truncation distance in voxels (reference: 3). */
+int dt_sparse_block_voxels(void);
+int dt_sparse_integrate_f32(int* dir, unsigned char* touch, int nb, float voxel_size, int* keys, float* tsdf, float* weight,
+                            int* count2, int capacity, const float* depth_hw, int img_h, int img_w, const float* K44_host,
+                            const float* cam_T_world44_host, float max_depth, float trunc_voxels, int extended_neg_truncation,
+                            dt_stream_t s);
+/* trilinear sample of the tsdf (what=0) or weight (what=1) field at world points; unallocated corners read 0 */
+int dt_sparse_sample_f32(int* dir, unsigned char* touch, int nb, float voxel_size, int* keys, float* tsdf, float* weight,
+                         int* count2, int capacity, const float* points_N3, float* out_N, int64_t n, int what, dt_stream_t s);
+/* replaces: VoxelBlockGrid.extract_triangle_mesh(weight_threshold) (:451-481): marching cubes over the first num_slots
+ * slots; a cell is meshed when all 8 corners are allocated with weight > weight_threshold.  Two phases like dt_mc_*:
+ * count fills slot_offsets[num_slots] (exclusive scan) and total_out[0] = vertex count; generate writes world-space
+ * vertices [V,3], per-vertex interpolated weights [V] (may be NULL), faces [V/3,3] and int64 edge ids [V]. */
+int dt_sparse_mc_count(int* dir, unsigned char* touch, int nb, float voxel_size, int* keys, float* tsdf, float* weight, int* count2,
+                       int capacity, int num_slots, float isolevel, float weight_threshold, int* slot_offsets, int* total_out,
+                       dt_stream_t s);
+int dt_sparse_mc_generate(int* dir, unsigned char* touch, int nb, float voxel_size, int* keys, float* tsdf, float* weight,
+                          int* count2, int capacity, int num_slots, float isolevel, float weight_threshold, const int* slot_offsets,
+                          float* verts_v3, float* vert_weights_v, int64_t* faces_f3, int64_t* ids_v, int num_verts, dt_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif
