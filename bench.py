@@ -453,11 +453,19 @@ def main():
         flops = volume_flops(CFG["batch"], CFG["num_src"], h, w, CFG["planes"])
         achieved = flops / (kern_ms * 1e-3) / 1e12
         frames = args.steps * CFG["batch"] * world
-        traffic = None
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the figure comes from
+        # the last scripts/collect_pmc.sh pass -- and only while the kernel source it was measured on is the one built now
+        traffic, traffic_tag = None, None
         tf = os.path.join(REPO, "profiles", "roofline_traffic.json")
         if os.path.isfile(tf):
             try:
-                traffic = json.load(open(tf)).get("cv_mlp_mfma_kernel_hbm_bytes_per_launch")
+                import hashlib
+
+                rec = json.load(open(tf))
+                src = open(os.path.join(REPO, "doubletake_amd", "csrc", "cv_mlp_mfma.hip"), "rb").read()
+                if rec.get("kernel_source_sha16") == hashlib.sha256(src).hexdigest()[:16]:
+                    traffic = rec.get("cv_mlp_mfma_kernel_hbm_bytes_per_launch")
+                    traffic_tag = rec.get("profile_tag")
             except Exception:
                 traffic = None
         result = {
@@ -490,6 +498,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic,
+                "traffic_profile": traffic_tag,
                 "algorithmic_flops_per_launch": flops,
                 "avg_launch_ms": kern_ms,
             },

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(SPLIT >= 8 ? SPLIT * 64 : 256) void conv_mfma_kerne
   constexpr int IH = (kPH - 1) * ST + KS, IW = (kPW - 1) * ST + KS;
   constexpr int NPIX = IH * IW;
   constexpr int NLOAD = (NPIX + 31) / 32;  // float4 staging loads per lane and group
-  constexpr int TILE_FLOATS = (SPLIT == 1) ? NPIX * 8 : ((NPIX * 8 > 1024) ? NPIX * 8 : 1024);
+  constexpr int PATCH_FLOATS = (ST == 1) ? 2 * IH * 12 * 4 : NPIX * 8;  // (stride 1: padded row pitch, see below)
+  constexpr int TILE_FLOATS = (SPLIT == 1) ? PATCH_FLOATS : ((PATCH_FLOATS > 1024) ? PATCH_FLOATS : 1024);
   constexpr int PAD = KS / 2;
   constexpr int TAPS = KS * KS;
   __shared__ __attribute__((aligned(16))) float lds[NW * TILE_FLOATS];
@@ -87,7 +88,17 @@ __global__ __launch_bounds__(SPLIT >= 8 ? SPLIT * 64 : 256) void conv_mfma_kerne
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, p = lane & 31;
-  const int py = p >> 3, px = p & 7;
+  // Stride 1: the staged patch is laid out [channel half][row][column, pitch 12][4 floats] and the lanes that one
+  // ds_read_b128 cycle services together ({0-3,12-15,20-27} / {4-11,16-19,28-31} of each half-wave) own pixel rows
+  // {0,2} / {1,3} of the 4x8 block, so the 16 lanes of an access touch 16 different four-bank groups (12*row + col mod
+  // 16).  The [pixel][8 channels] layout it replaces left SQ_LDS_BANK_CONFLICT at 63 % of this kernel's LDS cycles
+  // (profiles/r2i_pmc_summary.json).  Stride 2 keeps the pixel-major layout.
+  constexpr bool SWZ = (ST == 1);
+  constexpr int PITCH = 12;
+  const bool grp_a = (p < 4) || (p >= 12 && p < 16) || (p >= 20 && p < 28);
+  const int gi = grp_a ? ((p < 4) ? p : ((p < 16) ? p - 8 : p - 12)) : ((p < 12) ? p - 4 : ((p < 20) ? p - 8 : p - 16));
+  const int py = SWZ ? 2 * (gi >> 3) + (grp_a ? 0 : 1) : (p >> 3), px = SWZ ? (gi & 7) : (p & 7);
+  auto lds_off = [&](int hf, int row, int col) { return SWZ ? ((hf * IH + row) * PITCH + col) * 4 : (row * IW + col) * 8 + hf * 4; };
 
   const long total_blocks = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
   long bid = (SPLIT == 1) ? (long)blockIdx.x * 4 + wave : xcd_contiguous_block(a.xcd_remap);
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(SPLIT >= 8 ? SPLIT * 64 : 256) void conv_mfma_kerne
     __builtin_amdgcn_wave_barrier();                                                                 \
     _Pragma("unroll") for (int it = 0; it < NLOAD; ++it) {                                           \
       const int idx = (lane >> 1) + it * 32;                                                         \
-      if (idx < NPIX) *reinterpret_cast<float4*>(tile + idx * 8 + (lane & 1) * 4) = patch[it];       \
+      if (idx < NPIX) *reinterpret_cast<float4*>(tile + lds_off(lane & 1, idx / IW, idx % IW)) = patch[it]; \
     }                                                                                                \
     if ((G) + g_step < a.groups) {                                                                   \
       DT_PREFETCH_PATCH((G) + g_step);                                                               \
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(SPLIT >= 8 ? SPLIT * 64 : 256) void conv_mfma_kerne
     _Pragma("unroll") for (int t = 0; t < TAPS; ++t) {                                               \
       const int ky = t / KS, kx = t - ky * KS;                                                       \
       const float4 b4 = (DT_ABL & 4) ? make_float4(acc[0], acc[1], 1.f, (float)t) :                  \
-          *reinterpret_cast<const float4*>(tile + ((py * ST + ky) * IW + (px * ST + kx)) * 8 + half * 4); \
+          *reinterpret_cast<const float4*>(tile + lds_off(half, py * ST + ky, px * ST + kx));           \
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WCUR[t].x, b4.x, acc, 0, 0, 0);                     \
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WCUR[t].y, b4.y, acc, 0, 0, 0);                     \
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WCUR[t].z, b4.z, acc, 0, 0, 0);                     \
@@ -491,7 +502,18 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
 #endif
 constexpr int kWinoTH = 4, kWinoTW = 8;                      // Winograd tiles per workgroup (rows, cols)
 constexpr int kWinoPH = 2 * kWinoTH + 2, kWinoPW = 2 * kWinoTW + 2;  // staged input patch 10 x 18
-constexpr int kWinoPatchFloats = kWinoPH * kWinoPW * 8;
+// LDS layout of a staged 8-channel patch: [channel half][column parity][row (10)][column / 2, pitch 10][4 floats].
+// A lane reads, for a fixed (row offset r, column offset c), pixel (2*ty + r, 2*tx + c) of ITS channel half: with the
+// plain [pixel][8 channels] layout the 16 lanes that one ds_read_b128 cycle services touch only 4 of the 16 four-bank
+// groups (stride 64 B in tx, half the bytes of every pixel unused) -- SQ_LDS_BANK_CONFLICT was 64 % of the kernel's LDS
+// cycles (profiles/r2i_pmc_summary.json).  Splitting halves and column parities makes tx advance by one 16-byte slot,
+// a row pair by 20 slots (= 4 mod 16), and the lane -> tile map below puts tile rows {0,2} / {1,3} into the two lane
+// groups of a b128 access: every access is conflict free.
+constexpr int kWinoRowPitch = 10;  // columns per parity (9 used), padded so that two rows shift the bank group by 4
+constexpr int kWinoPatchFloats = 2 * 2 * kWinoPH * kWinoRowPitch * 4;  // 1600
+__device__ __forceinline__ int wino_lds_off(int half, int y, int x) {
+  return ((((half * 2 + (x & 1)) * kWinoPH + y) * kWinoRowPitch) + (x >> 1)) * 4;
+}
 
 // KSPLIT > 1: KSPLIT groups of four waves take the 8-channel groups round-robin (each with its own patch
 // buffers) and their partial results are summed in the row-inverse step; for layers with too few output
@@ -508,7 +530,11 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs 
   const int ks = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));  // K-split group
   float* lds = lds_all + ks * 8192;
   const int half = lane >> 5, t = lane & 31;
-  const int ty = t >> 3, tx = t & 7;
+  // lane -> Winograd tile: ds_read_b128 services lanes {0-3,12-15,20-27} and {4-11,16-19,28-31} (of each half-wave)
+  // together; the first group takes tile rows 0 and 2, the second rows 1 and 3 (see wino_lds_off)
+  const bool grp_a = (t < 4) || (t >= 12 && t < 16) || (t >= 20 && t < 28);
+  const int gi = grp_a ? ((t < 4) ? t : ((t < 16) ? t - 8 : t - 12)) : ((t < 12) ? t - 4 : ((t < 20) ? t - 8 : t - 16));
+  const int ty = 2 * (gi >> 3) + (grp_a ? 0 : 1), tx = gi & 7;
 
   const int wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
   long bid = xcd_contiguous_block(a.xcd_remap);
@@ -553,7 +579,13 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs 
   const int r1 = (wave == 0) ? 0 : ((wave == 2) ? 2 : 1);
   const int r2 = (wave == 0) ? 2 : ((wave == 1) ? 2 : ((wave == 2) ? 1 : 3));
   const float sgn = (wave == 1) ? 1.0f : -1.0f;
-  const int win = ((2 * ty) * kWinoPW + 2 * tx) * 8 + half * 4;  // window origin of this lane's tile in the patch
+  // LDS offsets of the eight window positions this lane reads per group: rows r1 / r2, columns 0..3
+  int wo1[4], wo2[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    wo1[c] = wino_lds_off(half, 2 * ty + r1, 2 * tx + c);
+    wo2[c] = wino_lds_off(half, 2 * ty + r2, 2 * tx + c);
+  }
 
   float4 patch[NLOAD];
   float4 w[4];
@@ -590,7 +622,8 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs 
     for (int it = 0; it < NLOAD; ++it) {
       const int idx = (tid >> 1) + it * 128;
       if (idx < NPIX)
-        *reinterpret_cast<float4*>(buf + idx * 8 + (tid & 1) * 4) = live_g ? patch[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(buf + wino_lds_off(tid & 1, idx / kWinoPW, idx % kWinoPW)) =
+            live_g ? patch[it] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float4 wc[4];
 #pragma unroll
@@ -602,9 +635,9 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float4 u = (DT_WABL & 4) ? make_float4(acc[0][c], 1.f, 2.f, (float)g)
-                                     : *reinterpret_cast<const float4*>(buf + win + (r1 * kWinoPW + c) * 8);
+                                     : *reinterpret_cast<const float4*>(buf + wo1[c]);
       const float4 v = (DT_WABL & 4) ? make_float4(acc[1][c], 3.f, 1.f, (float)c)
-                                     : *reinterpret_cast<const float4*>(buf + win + (r2 * kWinoPW + c) * 8);
+                                     : *reinterpret_cast<const float4*>(buf + wo2[c]);
       tcol[c] = make_float4(u.x + sgn * v.x, u.y + sgn * v.y, u.z + sgn * v.z, u.w + sgn * v.w);
     }
     float4 V[4];
