@@ -58,6 +58,7 @@ SIGNATURES = {
     "dt_conv_wino_pack_floats": (_L, [_I, _I]),
     "dt_conv_wino_pack_f32": (_I, [_P, _P, _I, _I, _P]),
     "dt_conv2d_wino_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dt_conv2d_pair_f32": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "dt_conv2d_simple_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "dt_conv1x1_head_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "dt_head_mlp_pack_floats": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
@@ -139,6 +140,13 @@ def ptr(t):
 
 
 def current_stream(device=None):
+    """HIP stream handle of torch's current stream on ``device``.  The library launches on that stream without a device
+    guard of its own, so HIP's current device is switched to ``device`` here if it differs (one process per GPU is the
+    intended deployment; this keeps a single process that touches several GPUs correct as well)."""
     import torch
 
+    if device is not None:
+        idx = torch.device(device).index
+        if idx is not None and idx != torch.cuda.current_device():
+            torch.cuda.set_device(idx)
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -51,8 +51,7 @@ constexpr int kPH = 4, kPW = 8;  // output patch of one MFMA pixel block
 // Workgroups are dealt round-robin to the 8 XCDs (each with a private L2).  Map the hardware block index to
 // a logical one so that every XCD works on one contiguous eighth of the block space: the co-blocks of a pixel
 // tile and its neighbouring tiles (shared input halo) then hit the same L2 instead of eight different ones.
-__device__ __forceinline__ long xcd_contiguous_block(int xcd_remap) {
-  const unsigned nb = gridDim.x, b = blockIdx.x;
+__device__ __forceinline__ long xcd_contiguous_block(int xcd_remap, unsigned b, unsigned nb) {
   if (!xcd_remap || (nb & 7u) != 0u) return (long)b;
   return (long)(b & 7u) * (nb >> 3) + (b >> 3);
 }
@@ -74,16 +73,27 @@ __device__ __forceinline__ int pixel_offset(bool inside, int n, int iy, int ix, 
 //   16 : one block per 1024-thread workgroup, 16-way K split (only the low-resolution 1x1 downsample convs:
 //        for the 3x3 layers of the 15x20 level it measured 10 % slower than 8)
 template <int KS, int ST, int SPLIT>
-__global__ __launch_bounds__(SPLIT >= 8 ? SPLIT * 64 : 256) void conv_mfma_kernel(const ConvArgs a) {
-  constexpr int NW = (SPLIT >= 8) ? SPLIT : 4;
-  constexpr int IH = (kPH - 1) * ST + KS, IW = (kPW - 1) * ST + KS;
-  constexpr int NPIX = IH * IW;
+struct ConvMfmaCfg {
+  static constexpr int NW = (SPLIT >= 8) ? SPLIT : 4;
+  static constexpr int IH = (kPH - 1) * ST + KS, IW = (kPW - 1) * ST + KS;
+  static constexpr int NPIX = IH * IW;
+  static constexpr int PATCH_FLOATS = (ST == 1) ? 2 * IH * 12 * 4 : NPIX * 8;  // (stride 1: padded row pitch, see the body)
+  static constexpr int TILE_FLOATS = (SPLIT == 1) ? PATCH_FLOATS : ((PATCH_FLOATS > 1024) ? PATCH_FLOATS : 1024);
+  static constexpr int LDS_FLOATS = NW * TILE_FLOATS;
+  static constexpr int THREADS = NW * 64;
+};
+
+// The body takes a VIRTUAL block index / grid size so that two convolutions can share one launch (conv_pair_kernel).
+template <int KS, int ST, int SPLIT>
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restrict__ lds, unsigned vblock, unsigned vgrid) {
+  using Cfg = ConvMfmaCfg<KS, ST, SPLIT>;
+  constexpr int NW = Cfg::NW;
+  constexpr int IH = Cfg::IH, IW = Cfg::IW;
+  constexpr int NPIX = Cfg::NPIX;
   constexpr int NLOAD = (NPIX + 31) / 32;  // float4 staging loads per lane and group
-  constexpr int PATCH_FLOATS = (ST == 1) ? 2 * IH * 12 * 4 : NPIX * 8;  // (stride 1: padded row pitch, see below)
-  constexpr int TILE_FLOATS = (SPLIT == 1) ? PATCH_FLOATS : ((PATCH_FLOATS > 1024) ? PATCH_FLOATS : 1024);
+  constexpr int TILE_FLOATS = Cfg::TILE_FLOATS;
   constexpr int PAD = KS / 2;
   constexpr int TAPS = KS * KS;
-  __shared__ __attribute__((aligned(16))) float lds[NW * TILE_FLOATS];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(SPLIT >= 8 ? SPLIT * 64 : 256) void conv_mfma_kerne
   auto lds_off = [&](int hf, int row, int col) { return SWZ ? ((hf * IH + row) * PITCH + col) * 4 : (row * IW + col) * 8 + hf * 4; };
 
   const long total_blocks = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
-  long bid = (SPLIT == 1) ? (long)blockIdx.x * 4 + wave : xcd_contiguous_block(a.xcd_remap);
+  long bid = (SPLIT == 1) ? (long)vblock * 4 + wave : xcd_contiguous_block(a.xcd_remap, vblock, vgrid);
   const bool have_block = bid < total_blocks;
   if (!have_block) bid = total_blocks - 1;  // keep the wave alive (no barriers are skipped); it stores nothing
   int cb;
@@ -280,6 +290,12 @@ __global__ __launch_bounds__(SPLIT >= 8 ? SPLIT * 64 : 256) void conv_mfma_kerne
   }
 }
 
+template <int KS, int ST, int SPLIT>
+__global__ __launch_bounds__((ConvMfmaCfg<KS, ST, SPLIT>::THREADS)) void conv_mfma_kernel(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[ConvMfmaCfg<KS, ST, SPLIT>::LDS_FLOATS];
+  conv_mfma_body<KS, ST, SPLIT>(a, lds, blockIdx.x, gridDim.x);
+}
+
 // ---- many-block layers: four pixel tiles per workgroup share the weight fragments through LDS -------
 // Ablation on the 240x320 128->64 layer (scripts/time_conv_layer.py, -DDT_ABL): of 139 us, 30 us were
 // stalls on the per-wave weight loads (every wave re-read all 147 KB of its channel block's weights
@@ -414,13 +430,13 @@ __global__ __launch_bounds__(256) void conv_mfma_wshare_kernel(const ConvArgs a)
 // loads its own B fragment (4 consecutive channels) directly, so nothing is staged and eight
 // 8-channel groups (16 dwordx4 loads per lane) are issued before their 32 MFMAs -- with one tap per
 // group there is no other way to cover the load latency.  One wave = one 32-channel x 32-pixel block.
-__global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv1x1_mfma_body(const ConvArgs& a, unsigned vblock) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, p = lane & 31;
   const long npix = (long)a.n * a.h_out * a.w_out;
   const long pix_blocks = (npix + 31) / 32;
-  long bid = (long)blockIdx.x * 4 + wave;
+  long bid = (long)vblock * 4 + wave;
   const bool have_block = bid < pix_blocks * a.co_blocks;
   if (!have_block) bid = pix_blocks * a.co_blocks - 1;
   const int cb = (int)(bid % a.co_blocks);
@@ -488,6 +504,8 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) { conv1x1_mfma_body(a, blockIdx.x); }
+
 // ---- Winograd F(2x2, 3x3) variant of the 3x3 stride-1 conv -------------------------------------------
 // Y = A^T [ (G g G^T) .* (B^T d B) ] A per 4x4 input window / 2x2 output tile: 16 multiplies instead of 36,
 // i.e. 2.25x fewer MFMAs.  Mapping: a workgroup owns 8x16 output pixels = 4x8 Winograd tiles (the MFMA N
@@ -519,11 +537,10 @@ __device__ __forceinline__ int wino_lds_off(int half, int y, int x) {
 // buffers) and their partial results are summed in the row-inverse step; for layers with too few output
 // blocks to fill the chip.
 template <int KSPLIT>
-__global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restrict__ lds_all, unsigned vblock, unsigned vgrid) {
   constexpr int NPIX = kWinoPH * kWinoPW;  // 180
   constexpr int NLOAD = (NPIX + 127) / 128;  // float4 staging loads per thread and group
-  // per K-split group: 2 patch buffers (2 x 1440 floats), later 4 waves x 2 x 1024 Z values
-  __shared__ __attribute__((aligned(16))) float lds_all[8192 * KSPLIT];
+  // lds_all: 8192 floats per K-split group: 2 patch buffers (2 x 1600 floats), later 4 waves x 2 x 1024 Z values
   const int tid = threadIdx.x & 255;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // transform row of this wave
@@ -537,7 +554,7 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs 
   const int ty = 2 * (gi >> 3) + (grp_a ? 0 : 1), tx = gi & 7;
 
   const int wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
-  long bid = xcd_contiguous_block(a.xcd_remap);
+  long bid = xcd_contiguous_block(a.xcd_remap, vblock, vgrid);
   const int cb = (int)(bid % a.co_blocks);
   bid /= a.co_blocks;
   const int bx = (int)(bid % wt_x);
@@ -704,6 +721,44 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs 
   }
 }
 
+template <int KSPLIT>
+__global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds_all[8192 * KSPLIT];
+  conv_wino_body<KSPLIT>(a, lds_all, blockIdx.x, gridDim.x);
+}
+
+// ---- two independent convolutions of the SAME input in one launch ------------------------------------------------------
+// BasicBlock (reference modules/layers.py:77-94) runs conv1 and the shortcut conv ("downsample": 1x1, or 3x3 stride 2)
+// on the same input.  As two launches the second one costs a full kernel boundary (~5-7 us on the GPU for layers whose
+// arithmetic is 1-3 us) although nothing depends on it until conv2.  Here the workgroups of both share one grid:
+// blocks [0, nblocks_a) run convolution A, the rest convolution B, each with its own ConvArgs and virtual block index.
+// Both bodies must use the same workgroup size.
+template <class BodyA, class BodyB>
+__global__ __launch_bounds__(BodyA::THREADS) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, unsigned nblocks_a) {
+  static_assert(BodyA::THREADS == BodyB::THREADS, "paired convolutions need equal workgroup sizes");
+  constexpr int LDSF = BodyA::LDS_FLOATS > BodyB::LDS_FLOATS ? BodyA::LDS_FLOATS : BodyB::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF > 0 ? LDSF : 4];
+  if (blockIdx.x < nblocks_a) BodyA::run(a, lds, blockIdx.x, nblocks_a);
+  else BodyB::run(b, lds, blockIdx.x - nblocks_a, gridDim.x - nblocks_a);
+}
+template <int KS, int ST, int SPLIT>
+struct MfmaBody {
+  static constexpr int THREADS = ConvMfmaCfg<KS, ST, SPLIT>::THREADS;
+  static constexpr int LDS_FLOATS = ConvMfmaCfg<KS, ST, SPLIT>::LDS_FLOATS;
+  static __device__ __forceinline__ void run(const ConvArgs& a, float* lds, unsigned vb, unsigned vg) { conv_mfma_body<KS, ST, SPLIT>(a, lds, vb, vg); }
+};
+template <int KSPLIT>
+struct WinoBody {
+  static constexpr int THREADS = 256 * KSPLIT;
+  static constexpr int LDS_FLOATS = 8192 * KSPLIT;
+  static __device__ __forceinline__ void run(const ConvArgs& a, float* lds, unsigned vb, unsigned vg) { conv_wino_body<KSPLIT>(a, lds, vb, vg); }
+};
+struct OneByOneBody {
+  static constexpr int THREADS = 256;
+  static constexpr int LDS_FLOATS = 0;
+  static __device__ __forceinline__ void run(const ConvArgs& a, float*, unsigned vb, unsigned) { conv1x1_mfma_body(a, vb); }
+};
+
 // OIHW 3x3 weights -> U = G g G^T per (co, ci), packed [co_block][group][xi][half][32][4]
 __global__ void conv_wino_pack_kernel(const float* __restrict__ W, float* __restrict__ packed, int c_out, int c_in) {
   const int groups = c_in >> 3;
@@ -856,7 +911,7 @@ __global__ void upsample2x_bilinear_kernel(const float* __restrict__ in, float* 
 }
 
 static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* bias,
-                     const float* res, float* out, ConvArgs& a, const char* who) {
+                     const float* res, float* out, ConvArgs& a, const char* who, bool any_channels = false) {
   DT_REQUIRE(d != nullptr, "%s: null descriptor", who);
   DT_REQUIRE(d->n > 0 && d->h_out > 0 && d->w_out > 0 && d->h_in > 0 && d->w_in > 0, "%s: bad extents", who);
   DT_REQUIRE(d->nsrc >= 1 && d->nsrc <= 3, "%s: nsrc=%d not in 1..3", who, d->nsrc);
@@ -879,7 +934,8 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
   }
   for (int s = 0; s < d->nsrc; ++s) {
     DT_REQUIRE(ins[s] != nullptr, "%s: source %d is null", who, s);
-    DT_REQUIRE(d->c[s] > 0 && d->c[s] % 8 == 0, "%s: source %d has %d channels (multiple of 8 required)", who, s, d->c[s]);
+    DT_REQUIRE(d->c[s] > 0 && (any_channels || d->c[s] % 8 == 0), "%s: source %d has %d channels (multiple of 8 required)", who,
+               s, d->c[s]);
     DT_REQUIRE(!d->up[s] || (d->h_in % 2 == 0 && d->w_in % 2 == 0), "%s: upsampled source needs even input extent", who);
     a.src[s] = ins[s];
     a.c[s] = d->c[s];
@@ -1018,10 +1074,84 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
   return check_launch("dt_conv2d_wino_f32");
 }
 
+// kernel the single-launch entry points would pick (kept in one place so that the pair launcher agrees with them)
+enum ConvPick { PICK_WSHARE, PICK_SPLIT4, PICK_SPLIT8, PICK_1X1_PLAIN, PICK_1X1_SPLIT8, PICK_1X1_SPLIT16 };
+static ConvPick pick_direct(const ConvArgs& a, const dt_conv_desc* d) {
+  const long blocks = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
+  if (d->ksize == 3) {
+    const long k_steps = (long)a.groups * 9;
+    if (blocks >= 4096 || k_steps <= 16) return PICK_WSHARE;
+    if (blocks * 4 < 2048 && a.groups >= 16) return PICK_SPLIT8;
+    return PICK_SPLIT4;
+  }
+  const long pix_blocks = ((long)a.n * a.h_out * a.w_out + 31) / 32;
+  const long waves = pix_blocks * a.co_blocks;
+  if (waves < 1024 && a.groups >= 32 && blocks * 8 < 2048) return PICK_1X1_SPLIT16;
+  if (waves < 1024 && a.groups >= 16) return PICK_1X1_SPLIT8;
+  return PICK_1X1_PLAIN;
+}
+
+/* conv1 and the shortcut conv of a BasicBlock (modules/layers.py:77-94) in ONE launch: both read the same sources.
+ * A: 3x3 (stride 1 or 2), packed for the Winograd kernel when a_wino != 0 (stride 1 only) else for the direct kernel;
+ * B: 1x1 stride 1 (when A has stride 1) or 3x3 stride 2 (when A has stride 2), direct packing.  Combinations whose two
+ * kernels do not share a workgroup size fall back to two launches inside this call (same results either way). */
+int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const float* in0, const float* in1, const float* in2,
+                       const float* packed_wa, int a_wino, const float* bias_a, float* out_a, const float* packed_wb,
+                       const float* bias_b, float* out_b, dt_stream_t s) {
+  ConvArgs a, b;
+  if (int rc = fill_args(da, in0, in1, in2, bias_a, nullptr, out_a, a, "dt_conv2d_pair_f32(A)")) return rc;
+  if (int rc = fill_args(db, in0, in1, in2, bias_b, nullptr, out_b, b, "dt_conv2d_pair_f32(B)")) return rc;
+  DT_REQUIRE(packed_wa && packed_wb, "dt_conv2d_pair_f32: null weights");
+  DT_REQUIRE(da->c_out % 32 == 0 && db->c_out % 32 == 0, "dt_conv2d_pair_f32: c_out must be a multiple of 32");
+  DT_REQUIRE(da->ksize == 3 && da->stride == db->stride && da->h_out == db->h_out && da->w_out == db->w_out && da->n == db->n,
+             "dt_conv2d_pair_f32: A must be 3x3 and both convolutions must produce the same extent");
+  DT_REQUIRE((db->ksize == 1 && db->stride == 1) || (db->ksize == 3 && db->stride == 2),
+             "dt_conv2d_pair_f32: B must be a 1x1 stride-1 or a 3x3 stride-2 convolution");
+  DT_REQUIRE(!a_wino || da->stride == 1, "dt_conv2d_pair_f32: the Winograd kernel needs stride 1");
+  a.wp = packed_wa;
+  b.wp = packed_wb;
+  hipStream_t st = to_stream(s);
+  const long blocks_b = (long)b.n * b.tiles_y * b.tiles_x * b.co_blocks;
+  const ConvPick pb = pick_direct(b, db);
+  using M118 = MfmaBody<1, 1, 8>;
+  using M318 = MfmaBody<3, 1, 8>;
+  using M328 = MfmaBody<3, 2, 8>;
+  using M324 = MfmaBody<3, 2, 4>;
+#define DT_PAIR(BA, BB, NA, NB)                                                                                           \
+  do {                                                                                                                    \
+    hipLaunchKernelGGL((conv_pair_kernel<BA, BB>), dim3((unsigned)((NA) + (NB))), dim3(BA::THREADS), 0, st, a, b,         \
+                       (unsigned)(NA));                                                                                   \
+    return check_launch("dt_conv2d_pair_f32");                                                                            \
+  } while (0)
+  if (a_wino) {
+    const long wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
+    const long blocks_a = (long)a.n * wt_y * wt_x * a.co_blocks;
+    const int ksplit = (blocks_a < 256 && a.groups >= 8) ? 2 : 1;
+    if (ksplit == 1 && pb == PICK_1X1_PLAIN) {
+      const long pix_blocks = ((long)b.n * b.h_out * b.w_out + 31) / 32;
+      DT_PAIR(WinoBody<1>, OneByOneBody, blocks_a, (pix_blocks * b.co_blocks + 3) / 4);
+    }
+    if (ksplit == 2 && (pb == PICK_1X1_SPLIT8 || pb == PICK_1X1_SPLIT16)) DT_PAIR(WinoBody<2>, M118, blocks_a, blocks_b);
+  } else {
+    const long blocks_a = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
+    const ConvPick pa = pick_direct(a, da);
+    if (da->stride == 1 && pa == PICK_SPLIT8 && (pb == PICK_1X1_SPLIT8 || pb == PICK_1X1_SPLIT16))
+      DT_PAIR(M318, M118, blocks_a, blocks_b);
+    if (da->stride == 2 && pa == PICK_SPLIT8 && pb == PICK_SPLIT8) DT_PAIR(M328, M328, blocks_a, blocks_b);
+    if (da->stride == 2 && pa == PICK_SPLIT4 && pb == PICK_SPLIT4) DT_PAIR(M324, M324, blocks_a, blocks_b);
+  }
+#undef DT_PAIR
+  // no common workgroup shape: two launches
+  int rc = a_wino ? dt_conv2d_wino_f32(da, in0, in1, in2, packed_wa, bias_a, nullptr, out_a, s)
+                  : dt_conv2d_f32(da, in0, in1, in2, packed_wa, bias_a, nullptr, out_a, s);
+  if (rc) return rc;
+  return dt_conv2d_f32(db, in0, in1, in2, packed_wb, bias_b, nullptr, out_b, s);
+}
+
 int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* W,
                          const float* bias, const float* residual, float* out, dt_stream_t s) {
   ConvArgs a;
-  if (int rc = fill_args(d, in0, in1, in2, bias, residual, out, a, "dt_conv2d_simple_f32")) return rc;
+  if (int rc = fill_args(d, in0, in1, in2, bias, residual, out, a, "dt_conv2d_simple_f32", /*any_channels=*/true)) return rc;
   DT_REQUIRE(W != nullptr, "dt_conv2d_simple_f32: null weights");
   DT_REQUIRE(d->c_out > 0, "dt_conv2d_simple_f32: c_out=%d", d->c_out);
   const size_t total = (size_t)a.n * a.h_out * a.w_out * a.c_out;

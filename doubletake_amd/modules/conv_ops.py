@@ -151,6 +151,10 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
     if residual is not None and (not _is_nhwc(residual) or tuple(residual.shape) != tuple(out.shape)):
         raise ValueError("residual must be NHWC with the output's shape")
     stream = _abi.current_stream(dev)
+    if impl == "mfma" and (co % 32 != 0 or any(d.c[i] % 8 != 0 for i in range(len(srcs)))):
+        # channel counts the 32-channel x 8-channel-group MFMA tiling cannot express (the reference's own
+        # configurations never produce them): the general-shape kernel, same fused epilogue
+        impl = "simple"
     if impl == "mfma" and k == 3 and st == 1 and co % 32 == 0 and WINO_MIN_BLOCKS > 0:
         wino_blocks = n * ((d.h_out + 7) // 8) * ((d.w_out + 15) // 16) * (co // 32)
         if wino_blocks >= WINO_MIN_BLOCKS:
@@ -168,6 +172,59 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
         _abi.check(L.dt_conv2d_simple_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wd), _abi.ptr(bias),
                                           _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_simple_f32")
     return out
+
+
+def _fill_desc(srcs, conv, act):
+    x0, up0 = srcs[0]
+    n = x0.shape[0]
+    h_in = x0.shape[2] * (2 if up0 else 1)
+    w_in = x0.shape[3] * (2 if up0 else 1)
+    k, st = conv.kernel_size[0], conv.stride[0]
+    d = _abi.ConvDesc()
+    d.n, d.c_out, d.nsrc, d.ksize, d.stride, d.act = n, conv.out_channels, len(srcs), k, st, act
+    d.h_in, d.w_in = h_in, w_in
+    d.pad_mode = 1 if conv.padding_mode == "replicate" else 0
+    pad = k // 2
+    d.h_out = (h_in + 2 * pad - k) // st + 1
+    d.w_out = (w_in + 2 * pad - k) // st + 1
+    for i, (t, up) in enumerate(srcs):
+        d.c[i] = t.shape[1]
+        d.up[i] = 1 if up else 0
+    return d
+
+
+#: launch conv1 and the shortcut conv of a BasicBlock as one kernel (DT_CONV_PAIR=0 restores two launches; A/B switch)
+PAIR_LAUNCH = _os.environ.get("DT_CONV_PAIR", "1") != "0"
+
+
+def conv2d_pair(srcs, conv_a: nn.Conv2d, act_a, conv_b: nn.Conv2d, act_b):
+    """Two convolutions of the same (virtually concatenated) sources in one launch (dt_conv2d_pair_f32): the 3x3 ``conv_a``
+    and the shortcut ``conv_b`` (1x1 stride 1, or 3x3 stride 2) of a BasicBlock.  Returns (out_a, out_b), equal bit for bit
+    to two conv2d calls.  Shapes the paired kernel cannot take go through two conv2d calls."""
+    co_a, co_b = conv_a.out_channels, conv_b.out_channels
+    ka, sa, kb, sb = conv_a.kernel_size[0], conv_a.stride[0], conv_b.kernel_size[0], conv_b.stride[0]
+    ok = (PAIR_LAUNCH and ka == 3 and sa == sb and co_a % 32 == 0 and co_b % 32 == 0 and all(t.shape[1] % 8 == 0 for t, _ in srcs)
+          and ((kb == 1 and sb == 1) or (kb == 3 and sb == 2)) and conv_a.padding_mode == "zeros" and conv_b.padding_mode == "zeros"
+          and all(_is_nhwc(t) for t, _ in srcs))
+    if not ok:
+        return conv2d(srcs, conv_a, act=act_a), conv2d(srcs, conv_b, act=act_b)
+    L = _abi.lib()
+    dev = srcs[0][0].device
+    da, db = _fill_desc(srcs, conv_a, act_a), _fill_desc(srcs, conv_b, act_b)
+    ptrs = [_abi.ptr(t) for t, _ in srcs] + [None] * (3 - len(srcs))
+    # same Winograd-vs-direct choice as conv2d makes for conv_a
+    a_wino = False
+    if sa == 1 and WINO_MIN_BLOCKS > 0:
+        a_wino = da.n * ((da.h_out + 7) // 8) * ((da.w_out + 15) // 16) * (co_a // 32) >= WINO_MIN_BLOCKS
+    wa = packed_weight_wino(conv_a, dev) if a_wino else packed_weight(conv_a, dev)
+    wb = packed_weight(conv_b, dev)
+    out_a = empty_nhwc(da.n, co_a, da.h_out, da.w_out, dev)
+    out_b = empty_nhwc(db.n, co_b, db.h_out, db.w_out, dev)
+    _abi.check(L.dt_conv2d_pair_f32(C.byref(da), C.byref(db), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wa), int(a_wino),
+                                    _abi.ptr(_dev_param(conv_a, "bias", dev)), _abi.ptr(out_a), _abi.ptr(wb),
+                                    _abi.ptr(_dev_param(conv_b, "bias", dev)), _abi.ptr(out_b), _abi.current_stream(dev)),
+               "dt_conv2d_pair_f32")
+    return out_a, out_b
 
 
 def conv1x1_head(x, conv: nn.Conv2d, with_exp=False):

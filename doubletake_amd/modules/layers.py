@@ -44,6 +44,10 @@ class BasicBlock(nn.Module):
 
     def run(self, srcs, impl="mfma"):
         """srcs: list of (NHWC tensor, nearest_up) forming the (virtually concatenated) block input."""
+        if self.downsample is not None and impl == "mfma":
+            # conv1 and the shortcut conv read the same input and nothing depends on the shortcut until conv2: one launch
+            t, identity = ops.conv2d_pair(srcs, self.conv1, ops.ACT_LRELU02, self.downsample[0], ops.ACT_NONE)
+            return ops.conv2d([(t, False)], self.conv2, act=ops.ACT_LRELU02, residual=identity, impl=impl)
         t = ops.conv2d(srcs, self.conv1, act=ops.ACT_LRELU02, impl=impl)
         if self.downsample is not None:
             identity = ops.conv2d(srcs, self.downsample[0], act=ops.ACT_NONE, impl=impl)

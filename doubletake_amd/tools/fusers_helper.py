@@ -69,16 +69,19 @@ class DepthFuser:
 
 class OurFuser(DepthFuser):
     def __init__(self, gt_path="", fusion_resolution=0.04, max_fusion_depth=3, fuse_color=False,
-                 extended_neg_truncation=False, bounds=None):
-        """``bounds`` (dict xmin..zmax) is an extension for callers that know the extent without a mesh."""
+                 extended_neg_truncation=False, bounds=None, device=None):
+        """``bounds`` (dict xmin..zmax) is an extension for callers that know the extent without a mesh; ``device``
+        places the volume (default: the current GPU -- every frame fused later is moved to it)."""
         super().__init__(gt_path, fusion_resolution, max_fusion_depth, fuse_color)
-        if bounds is not None:
-            tsdf_pred = TSDF.from_bounds(bounds, voxel_size=fusion_resolution)
-        elif gt_path is not None and gt_path != "":
-            tsdf_pred = TSDF.from_mesh(_Verts(_mesh_vertices(gt_path)), voxel_size=fusion_resolution)
-        else:
-            b = {"xmin": -10.0, "xmax": 10.0, "ymin": -10.0, "ymax": 10.0, "zmin": -10.0, "zmax": 10.0}
-            tsdf_pred = TSDF.from_bounds(b, voxel_size=fusion_resolution)
+        if bounds is None and gt_path is not None and gt_path != "":
+            v = _mesh_vertices(gt_path)
+            bounds = {"xmin": v[:, 0].min(), "xmax": v[:, 0].max(), "ymin": v[:, 1].min(), "ymax": v[:, 1].max(),
+                      "zmin": v[:, 2].min(), "zmax": v[:, 2].max()}
+            for key in bounds:  # TSDF.from_mesh pads the mesh bounds by 3 voxels (tools/tsdf.py:99-120)
+                bounds[key] = float(bounds[key]) + (-3 if "min" in key else 3) * fusion_resolution
+        if bounds is None:
+            bounds = {"xmin": -10.0, "xmax": 10.0, "ymin": -10.0, "ymax": 10.0, "zmin": -10.0, "zmax": 10.0}
+        tsdf_pred = TSDF.from_bounds(bounds, voxel_size=fusion_resolution, device=device)
         self.extended_neg_truncation = extended_neg_truncation
         self.tsdf_fuser_pred = TSDFFuser(tsdf_pred, max_depth=max_fusion_depth)
 

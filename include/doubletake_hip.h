@@ -166,6 +166,14 @@ int dt_conv_wino_pack_f32(const float* W_oihw, float* packed, int c_out, int c_i
 int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2,
                        const float* packed_w, const float* bias, const float* residual,
                        float* out, dt_stream_t s);
+/* conv1 and the shortcut ("downsample") conv of a BasicBlock (modules/layers.py:77-94) in ONE launch: both read the
+ * same (virtually concatenated) sources.  A: 3x3, stride 1 or 2, weights packed by dt_conv_wino_pack_f32 when a_wino != 0
+ * (stride 1 only) else by dt_conv_pack_f32.  B: 1x1 stride 1 (with a stride-1 A) or 3x3 stride 2 (with a stride-2 A),
+ * weights packed by dt_conv_pack_f32.  da->act / db->act are applied per convolution; no residual inputs.  Kernel
+ * pairs without a common workgroup size are issued as two launches inside the call. */
+int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const float* in0, const float* in1, const float* in2,
+                       const float* packed_wa, int a_wino, const float* bias_a, float* out_a, const float* packed_wb,
+                       const float* bias_b, float* out_b, dt_stream_t s);
 /* direct (one thread per output element) version of the same primitive taking the
  * unpacked nn.Conv2d weight; GPU-side cross-check for the parity tests. */
 int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in0, const float* in1,

@@ -62,15 +62,23 @@ def test_loud_failures():
     m8 = FeatureMeshHintVolumeManager(8, 8, num_depth_bins=8, num_source_views=k).to(gu.dev())
     with pytest.raises(_abi.DoubletakeHipError, match="num_src"):
         m8(**gu.volume_call_args(t8), cv_depth_hint_dict=gu.hint_dict(t8))
-    # conv primitive: channel counts the MFMA tiling cannot express
-    conv = torch.nn.Conv2d(12, 32, 3, padding=1).to(gu.dev())
-    x = ops.as_nhwc(torch.zeros(1, 12, 8, 8, device=gu.dev()))
-    with pytest.raises(_abi.DoubletakeHipError, match="multiple of 8"):
-        ops.conv2d([(x, False)], conv)
+    # conv primitive: channel counts the MFMA tiling cannot express run on the general-shape kernel (same result as torch)
+    conv = torch.nn.Conv2d(12, 20, 3, padding=1).to(gu.dev())
+    xin = torch.from_numpy(syn.hash_normalish((1, 12, 8, 8), 3)).to(gu.dev())
+    got = ops.conv2d([(ops.as_nhwc(xin), False)], conv)
+    want = torch.nn.functional.conv2d(xin.cpu(), conv.weight.detach().cpu(), conv.bias.detach().cpu(), padding=1)
+    assert (got.cpu() - want).abs().max().item() < 1e-5
+    # ... but asking for the MFMA entry point directly with such a shape fails loudly, with a retrievable message
+    d = _abi.ConvDesc()
+    d.n, d.h_out, d.w_out, d.c_out, d.nsrc, d.ksize, d.stride, d.act, d.h_in, d.w_in = 1, 8, 8, 32, 1, 3, 1, 0, 8, 8
+    d.c[0] = 12
+    import ctypes
+
+    buf = torch.zeros(4096, device=gu.dev())
+    assert _abi.lib().dt_conv2d_f32(ctypes.byref(d), _abi.ptr(buf), None, None, _abi.ptr(buf), None, None, _abi.ptr(buf), None) != 0
+    assert "multiple of 8" in _abi.lib().dt_last_error().decode()
     with pytest.raises(_abi.DoubletakeHipError):
         ops.as_nhwc(torch.zeros(1, 8, 4, 4))
-    # the error text of the C side is retrievable
-    assert "multiple of 8" in _abi.lib().dt_last_error().decode()
 
 
 def test_decoder_and_encoder_take_nchw_inputs():

@@ -93,8 +93,7 @@ def test_basic_block_vs_reference_golden(name, cin, cout, stride):
     import gpu_util as gu
     from doubletake_amd.modules.layers import BasicBlock
 
-    if cout % 32:
-        pytest.skip("MFMA path needs c_out % 32 == 0; covered by the simple-kernel case below")
+    # (c_out = 16 does not fit the 32-channel MFMA tile: conv_ops routes those layers to the general-shape kernel)
     g = load_golden("networks.npz")
     blk = BasicBlock(cin, cout, stride=stride).to(gu.dev())
     gu.set_formula_weights(blk, 500 + cin + cout)
@@ -255,3 +254,38 @@ def test_winograd_conv_vs_direct(shape):
     got = ops.conv2d(srcs, conv, act=ops.ACT_LRELU02, residual=res, impl="wino")
     assert got.shape == want.shape
     assert (got - want).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,stride,h,w", [
+    (128, 64, 1, 120, 160),   # Winograd (4 waves) + plain 1x1
+    (256, 128, 1, 60, 80),    # Winograd K-split (8 waves) + K-split 1x1
+    (512, 256, 1, 30, 40),    # direct 8-way K-split + K-split 1x1
+    (896, 384, 1, 15, 20),    # same at the coarsest level (1x1 would pick the 16-way split on its own)
+    (64, 128, 2, 120, 160),   # stride 2: 3x3 s2 + 3x3 s2 shortcut
+    (256, 384, 2, 30, 40),
+    (24, 32, 1, 10, 12),      # small shapes: combinations without a common workgroup size fall back to two launches
+])
+def test_paired_conv_launch_equals_two_launches_bitwise(cin, cout, stride, h, w):
+    """BasicBlock's conv1 + shortcut conv in one launch (dt_conv2d_pair_f32) against the two separate launches."""
+    import gpu_util as gu
+    from doubletake_amd.modules import conv_ops as ops
+    from doubletake_amd.modules.layers import BasicBlock
+
+    blk = BasicBlock(cin, cout, stride=stride).to(gu.dev())
+    gu.set_formula_weights(blk, 77 + cin)
+    x = ops.as_nhwc(_t(syn.hash_normalish((1, cin, h, w), 5)))
+    # two sources (concat) for the stride-1 cases, as CVEncoder's conv_i.0 uses it
+    srcs = [(x[:, : cin // 2 // 8 * 8].contiguous(memory_format=torch.channels_last), False),
+            (x[:, cin // 2 // 8 * 8:].contiguous(memory_format=torch.channels_last), False)] if stride == 1 else [(x, False)]
+    a1, b1 = ops.conv2d_pair(srcs, blk.conv1, ops.ACT_LRELU02, blk.downsample[0], ops.ACT_NONE)
+    a2 = ops.conv2d(srcs, blk.conv1, act=ops.ACT_LRELU02)
+    b2 = ops.conv2d(srcs, blk.downsample[0], act=ops.ACT_NONE)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2)
+    if (cin, cout) == (896, 384):
+        # on its own this 1x1 runs the 16-way K split; paired with the 8-wave 3x3 it runs the 8-way split: another
+        # summation order of the same fp32 products
+        assert (b1 - b2).abs().max().item() < 2e-5
+    else:
+        assert torch.equal(b1, b2)
+    assert a1.abs().max().item() > 0.01 and b1.abs().max().item() > 0.01

@@ -67,7 +67,7 @@ def test_slots_follow_directory_order():
     keys = g.block_keys().cpu().numpy().astype(np.int64)
     h = g.nb // 2
     lin = ((keys[:, 0] + h) * g.nb + (keys[:, 1] + h)) * g.nb + (keys[:, 2] + h)
-    assert len(lin) > 20 and np.all(np.diff(lin) > 0)
+    assert len(lin) > 10 and np.all(np.diff(lin) > 0)
     f2, _, _, _ = _fuse(1)
     assert torch.equal(f2.volume.block_keys(), g.block_keys()) and torch.equal(f2.volume.tsdf, g.tsdf)
 
