@@ -140,9 +140,12 @@ struct TsdfConsts {
   float img_w_h, img_h_h;  // half(W), half(H) as float
 };
 
+// DEPTH32: the depth maps are fp32 and rounded to half on the fly (what OurFuser.fuse_frames's .half() does,
+// tools/fusers_helper.py:67-73, without a converting copy kernel in front of every integration)
+template <bool DEPTH32>
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restrict__ values, uint16_t* __restrict__ weights,
                                                             uint32_t* __restrict__ active, int X, int Y, int Z,
-                                                            const uint16_t* __restrict__ depth, int img_h, int img_w,
+                                                            const void* __restrict__ depth_any, int img_h, int img_w,
                                                             const float* __restrict__ fp_all, int num_frames,
                                                             const TsdfConsts c) {
   // num_frames frames are integrated IN ORDER per voxel (the update is order dependent through the half
@@ -194,8 +197,10 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
       const float iy = rh(rh(rh(rh(gy + 1.0f) * c.img_h_h) - 1.0f) / 2.0f);
       const float xn = rintf(ix), yn = rintf(iy);
       float sd = 0.f;
-      if (xn >= 0.f && xn < (float)img_w && yn >= 0.f && yn < (float)img_h)  // false for NaN/inf
-        sd = h2f(depth[((size_t)f * img_h + (int)yn) * img_w + (int)xn]);
+      if (xn >= 0.f && xn < (float)img_w && yn >= 0.f && yn < (float)img_h) {  // false for NaN/inf
+        const size_t di = ((size_t)f * img_h + (int)yn) * img_w + (int)xn;
+        sd = DEPTH32 ? rh(reinterpret_cast<const float*>(depth_any)[di]) : h2f(reinterpret_cast<const uint16_t*>(depth_any)[di]);
+      }
       const float vd = q[2];
       float t = rh(sd - c.min_depth);
       t = rh(t / c.depth_range);
@@ -341,9 +346,9 @@ int dt_tsdf_integrate_f16(uint16_t* values, uint16_t* weights, uint32_t* active,
                                       frame_params, th, s);
 }
 
-int dt_tsdf_integrate_frames_f16(uint16_t* values, uint16_t* weights, uint32_t* active, const float* origin3,
-                                 float voxel_size, int X, int Y, int Z, const uint16_t* depth, int num_frames, int img_h,
-                                 int img_w, const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s) {
+static int integrate_frames(uint16_t* values, uint16_t* weights, uint32_t* active, const float* origin3, float voxel_size, int X,
+                            int Y, int Z, const void* depth, bool depth32, int num_frames, int img_h, int img_w,
+                            const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s) {
   DT_REQUIRE(values && weights && active && origin3 && depth && frame_params && th, "dt_tsdf_integrate_f16: null pointer");
   DT_REQUIRE(X > 0 && Y > 0 && Z > 0 && img_h > 0 && img_w > 0 && voxel_size > 0.f && num_frames > 0,
              "dt_tsdf_integrate_f16: bad extents");
@@ -366,9 +371,28 @@ int dt_tsdf_integrate_frames_f16(uint16_t* values, uint16_t* weights, uint32_t* 
   const size_t slab = (size_t)Y * Z;
   DT_REQUIRE(slab % 64 == 0, "dt_tsdf_integrate_f16: Y*Z must be a multiple of 64 (dims are multiples of 8)");
   DT_REQUIRE(X <= 65535 && slab < 4294967040ull, "dt_tsdf_integrate_f16: volume too large for one launch");
-  hipLaunchKernelGGL(tsdf_integrate_kernel, dim3((unsigned)((slab + 255) / 256), (unsigned)X), dim3(256), 0, to_stream(s), values, weights, active, X,
-                     Y, Z, depth, img_h, img_w, frame_params, num_frames, c);
+  const dim3 grid((unsigned)((slab + 255) / 256), (unsigned)X);
+  if (depth32)
+    hipLaunchKernelGGL(tsdf_integrate_kernel<true>, grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, img_h,
+                       img_w, frame_params, num_frames, c);
+  else
+    hipLaunchKernelGGL(tsdf_integrate_kernel<false>, grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, img_h,
+                       img_w, frame_params, num_frames, c);
   return check_launch("dt_tsdf_integrate_f16");
+}
+
+int dt_tsdf_integrate_frames_f16(uint16_t* values, uint16_t* weights, uint32_t* active, const float* origin3,
+                                 float voxel_size, int X, int Y, int Z, const uint16_t* depth, int num_frames, int img_h,
+                                 int img_w, const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s) {
+  return integrate_frames(values, weights, active, origin3, voxel_size, X, Y, Z, depth, false, num_frames, img_h, img_w, frame_params,
+                          th, s);
+}
+
+int dt_tsdf_integrate_frames_f32depth_f16(uint16_t* values, uint16_t* weights, uint32_t* active, const float* origin3,
+                                          float voxel_size, int X, int Y, int Z, const float* depth_f32, int num_frames, int img_h,
+                                          int img_w, const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s) {
+  return integrate_frames(values, weights, active, origin3, voxel_size, X, Y, Z, depth_f32, true, num_frames, img_h, img_w,
+                          frame_params, th, s);
 }
 
 int dt_tsdf_sample_f16(const uint16_t* volume, const float* origin3, float voxel_size, int X, int Y, int Z,

@@ -207,7 +207,7 @@ class CostVolumeManager(nn.Module):
         m = torch.empty(shape, device=params.device, dtype=torch.uint8)
         _abi.check(L.dt_cv_overall_mask_u8(_abi.ptr(params), _abi.ptr(m), int(per_view), b, k, h, w, D, stream),
                    "dt_cv_overall_mask_u8")
-        return m.bool()
+        return m.view(torch.bool)  # bytes are 0/1: reinterpret, no copy kernel
 
     # -- forward -------------------------------------------------------------------------------
     def build_cost_volume(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth,

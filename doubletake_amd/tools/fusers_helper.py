@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import numpy as np
+import torch
 
 from .tsdf import TSDF, TSDFFuser
 
@@ -86,8 +87,10 @@ class OurFuser(DepthFuser):
         self.tsdf_fuser_pred = TSDFFuser(tsdf_pred, max_depth=max_fusion_depth)
 
     def fuse_frames(self, depths_b1hw, K_b44, cam_T_world_b44, color_b3hw=None):
+        # (fp32 depth maps are rounded to half inside the integrate kernel: same values as the reference's .half())
         self.tsdf_fuser_pred.integrate_depth(
-            depth_b1hw=depths_b1hw.half(), cam_T_world_T_b44=cam_T_world_b44.half(), K_b44=K_b44.half(),
+            depth_b1hw=depths_b1hw if depths_b1hw.dtype == torch.float32 else depths_b1hw.half(),
+            cam_T_world_T_b44=cam_T_world_b44.half(), K_b44=K_b44.half(),
             extended_neg_truncation=self.extended_neg_truncation)
 
     def export_mesh(self, path, export_single_mesh=True, trim_tsdf_using_confience=False):

@@ -298,7 +298,9 @@ class TSDFFuser:
         if depth_mask_b1hw is not None:
             depth = depth.clone()
             depth[~depth_mask_b1hw.to(dev)] = -1
-        depth = depth.half().contiguous()
+        # fp32 depth maps are rounded to half inside the kernel (same values as .half(), no converting copy)
+        depth32 = depth.dtype == torch.float32
+        depth = depth.contiguous() if depth32 else depth.half().contiguous()
         K16 = K_b44.to(dev).half().contiguous()
         T16 = cam_T_world_T_b44.to(dev).half().contiguous()
         img_h, img_w = depth.shape[2:]
@@ -314,7 +316,7 @@ class TSDFFuser:
         _abi.check(L.dt_tsdf_frames_setup_f16(_abi.ptr(K16), _abi.ptr(T16), nf, img_h, img_w, float(np.float32(depth_min)),
                                               float(np.float32(depth_max)), _abi.ptr(self._frame_params), stream),
                    "dt_tsdf_frames_setup_f16")
-        _abi.check(L.dt_tsdf_integrate_frames_f16(_abi.ptr(t.tsdf_values), _abi.ptr(t.tsdf_weights), _abi.ptr(t.voxel_bitmap), o,
-                                                  float(np.float32(t.voxel_size)), X, Y, Z, _abi.ptr(depth), nf, img_h, img_w,
-                                                  _abi.ptr(self._frame_params), C.byref(th), stream),
-                   "dt_tsdf_integrate_frames_f16")
+        entry = L.dt_tsdf_integrate_frames_f32depth_f16 if depth32 else L.dt_tsdf_integrate_frames_f16
+        _abi.check(entry(_abi.ptr(t.tsdf_values), _abi.ptr(t.tsdf_weights), _abi.ptr(t.voxel_bitmap), o,
+                         float(np.float32(t.voxel_size)), X, Y, Z, _abi.ptr(depth), nf, img_h, img_w,
+                         _abi.ptr(self._frame_params), C.byref(th), stream), "dt_tsdf_integrate_frames_f16")

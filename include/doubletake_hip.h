@@ -270,6 +270,12 @@ int dt_tsdf_integrate_frames_f16(uint16_t* values, uint16_t* weights, uint32_t* 
                                  const uint16_t* depth_f16, int num_frames, int img_h, int img_w,
                                  const float* frame_params, const dt_tsdf_thresholds* th,
                                  dt_stream_t s);
+/* the same with fp32 depth maps, rounded to half inside the kernel exactly as fuse_frames' .half() would
+ * (tools/fusers_helper.py:67-73): saves the converting copy in front of every integration */
+int dt_tsdf_integrate_frames_f32depth_f16(uint16_t* values, uint16_t* weights, uint32_t* active,
+                                          const float* origin3, float voxel_size, int X, int Y, int Z,
+                                          const float* depth_f32, int num_frames, int img_h, int img_w,
+                                          const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s);
 /* replaces: TSDF.sample_tsdf (tools/tsdf.py:277-339), trilinear, align_corners=True, zeros
  * padding.  fp16_math = 0 reproduces the reference's CPU branch (fp32 math on the half volume,
  * pinned by goldens); 1 rounds grid and result to half like its GPU branch (unpinned).
