@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void cv_warp_kernel(const float* __restrict__ 
 // simple MLP / hint volume: one thread per (pixel, plane); everything in plain fp32 loops.
 // Input-vector channel order follows modules/mesh_hint_volume.py:353-370.
 // ------------------------------------------------------------------------------------------
-constexpr int kMaxSrc = 8;
+constexpr int kMaxSrc = 16;
 constexpr int kFeat = 16;
 constexpr int kHidden = 128;
 

@@ -255,6 +255,9 @@ class FeatureVolumeManager(CostVolumeManager):
     #: optional callable(tag) invoked right before / after the fused kernel launch; bench.py uses
     #: it to record HIP events on the launch stream (roofline timing)
     _event_hook = None
+    #: source views the fused MFMA kernel handles (84 KB of layer-1 weights per 7 views stay in LDS)
+    MAX_FUSED_VIEWS = 7
+    _warned_views = False
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=None, matching_dim_size=16,
                  num_source_views=7):
@@ -283,8 +286,10 @@ class FeatureVolumeManager(CostVolumeManager):
         if hit == key:
             return self._pack_cache["val"]
         arrs = [a.float().cpu().numpy() for a in self._mlp_arrays(self.mlp)]
-        packed = mlp_pack.pack_mlp(*arrs, self.num_source_views)
-        val = {n: torch.from_numpy(v).to(device) for n, v in packed.items()}
+        val = {}
+        if self.num_source_views <= self.MAX_FUSED_VIEWS:
+            packed = mlp_pack.pack_mlp(*arrs, self.num_source_views)
+            val = {n: torch.from_numpy(v).to(device) for n, v in packed.items()}
         raw = self._mlp_arrays(self.mlp)
         val["raw"] = [_f32c(a.to(device)) for a in raw]
         if self._has_hint:
@@ -315,6 +320,16 @@ class FeatureVolumeManager(CostVolumeManager):
         if c != 16:
             raise ValueError("matching features must have 16 channels")
         dev = cur.device
+        if k > self.MAX_FUSED_VIEWS and _impl == "mfma":
+            # the fused MFMA kernel keeps the layer-1 weights of <= 7 views resident in LDS (the reference's default and
+            # every released checkpoint); more views run on the general kernel -- correct, but not the tuned path
+            if not FeatureVolumeManager._warned_views:
+                import warnings
+
+                warnings.warn(f"{k} source views: the fused MLP volume kernel covers up to {self.MAX_FUSED_VIEWS}; using the "
+                              "general (one thread per pixel and plane) HIP kernel", stacklevel=2)
+                FeatureVolumeManager._warned_views = True
+            _impl = "simple"
         pk = self._packed(dev)
         hint_ptr = hd = hw_ = hm = None
         H2 = W2 = 0
