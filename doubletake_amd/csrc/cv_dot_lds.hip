@@ -34,10 +34,12 @@
 // all take the direct global-memory path, which evaluates the same expressions in the same order: the staged and
 // the direct kernel produce bit-identical volumes (tests/test_volume_gpu.py).
 //
-// Measured (profiles/): cfg2 (B=1) 0.148 -> 0.106 ms; cfg3 (B=8, 512x384) 0.61 -> 0.32 ms.
+// Measured (profiles/): cfg2 (B=1) 0.148 -> 0.087 ms; cfg3 (B=8, 512x384) 0.61 -> 0.32 ms.
 // Ablations at cfg2: sampling only (no staging) 0.077 ms, staging only 0.099 ms -- at B=1 both are latency/tail
 // bound (600 workgroups, the near-plane groups split into many small boxes); at B=8 staging runs at the L2->LDS
 // rate (1.5 GB of boxes in 0.16 ms = 9 TB/s).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "cv_geometry.hpp"
 
@@ -352,9 +354,13 @@ static int dot_launch(int mode, const float* cur, const float* src, const float*
   if (num_src > 8) mode = 1;
   const int tiles = ((w + kDotTile - 1) / kDotTile) * ((h + kDotTile - 1) / kDotTile);
   const int wgs = (tiles + kDotWaves - 1) / kDotWaves;
-  // planes per wave: up to 8, fewer while the grid would not give every CU two workgroups
+  // planes per wave: up to 8, fewer while the grid has fewer than ~4 workgroups per CU -- the units differ a lot in cost
+  // (near planes split into many small boxes), so a B=1 frame needs the finer grain to balance: measured at cfg2
+  // 8 planes 0.105 ms, 4 planes 0.087 ms, 2 planes 0.091 ms; at B=8 (3072 workgroups with 8 planes) 8 planes stay best
   int group = kDotMaxGroup;
-  while (group > 2 && (long)wgs * batch * ((num_planes + group - 1) / group) < 512) group >>= 1;
+  while (group > 2 && (long)wgs * batch * ((num_planes + group - 1) / group) < 1024) group >>= 1;
+  static const int force_group = [] { const char* e = getenv("DT_DOT_GROUP"); return e ? atoi(e) : 0; }();  // tuning hook
+  if (force_group >= 1 && force_group <= kDotMaxGroup) group = force_group;
   dim3 grid(wgs, (num_planes + group - 1) / group, batch);
   if (mode == 0)
     hipLaunchKernelGGL(cv_dot_lds_kernel<0>, grid, dim3(64 * kDotWaves), 0, to_stream(s), cur, src, params, vol, num_src, h, w,
