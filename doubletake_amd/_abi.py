@@ -49,6 +49,8 @@ SIGNATURES = {
     "dt_cv_dot_stats_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dt_cv_mlp_pack_floats": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "dt_cv_mlp_hint_f32": (_I, [_P] * 11 + [_I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dt_cv_mlp_split_pack_halves": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "dt_cv_mlp_hint_split_f32": (_I, [_P] * 11 + [_I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dt_cv_mlp_hint_simple_f32": (_I, [_P] * 13 + [_I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "dt_cv_lowest_cost_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dt_cv_overall_mask_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -46,7 +46,13 @@
 namespace dt {
 
 constexpr int kDotTile = 8;            // a wave owns an 8 x 8 pixel tile, one pixel per lane
-constexpr int kDotCapTexels = 208;     // per-wave staged box: 208 texels x 64 B = 13 KB -> 52 KB per 4-wave workgroup, 3 per CU
+#ifndef DT_DOT_CAP
+#define DT_DOT_CAP 208
+#endif
+#ifndef DT_DOT_OCC
+#define DT_DOT_OCC 3
+#endif
+constexpr int kDotCapTexels = DT_DOT_CAP;  // per-wave staged box: 208 texels x 64 B = 13 KB -> 52 KB per 4-wave workgroup, 3 per CU
 constexpr int kDotMaxGroup = 8;        // planes per wave (accumulators per lane)
 constexpr int kDotWaves = 4;           // independent waves per workgroup (no workgroup barrier anywhere)
 
@@ -81,7 +87,7 @@ __device__ __forceinline__ float xor_max(float v, int m) { return fmaxf(v, __shf
 
 // MODE 0: LDS staging with direct fallback; MODE 1: direct path only (parity / ablation entry point)
 template <int MODE>
-__global__ __launch_bounds__(64 * kDotWaves, 3) void cv_dot_lds_kernel(const float* __restrict__ cur_bchw,
+__global__ __launch_bounds__(64 * kDotWaves, DT_DOT_OCC) void cv_dot_lds_kernel(const float* __restrict__ cur_bchw,
                                                                        const float* __restrict__ src_bkhwc,
                                                                        const float* __restrict__ params,
                                                                        float* __restrict__ vol, int K, int h, int w, int D,

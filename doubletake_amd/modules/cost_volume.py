@@ -22,6 +22,8 @@ library cannot be loaded.
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -258,6 +260,10 @@ class FeatureVolumeManager(CostVolumeManager):
     #: source views the fused MFMA kernel handles (84 KB of layer-1 weights per 7 views stay in LDS)
     MAX_FUSED_VIEWS = 7
     _warned_views = False
+    #: arithmetic of the fused MLP volume: "fp32" (default, exact fp32 MFMA) or "split16" (OPT-IN: fp16 hi/lo operands on
+    #: the fp16 matrix pipe, fp32-class accuracy, ~4x less matrix time; csrc/cv_mlp_split.hip).  Set on an instance
+    #: (`manager.precision = "split16"`) or for the process with DT_MLP_PRECISION=split16.
+    precision = os.environ.get("DT_MLP_PRECISION", "fp32")
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=None, matching_dim_size=16,
                  num_source_views=7):
@@ -281,7 +287,7 @@ class FeatureVolumeManager(CostVolumeManager):
 
     def _packed(self, device):
         params = list(self.mlp.parameters()) + (list(self.hint_mlp.parameters()) if self._has_hint else [])
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in params)
         hit = self._pack_cache.get("key")
         if hit == key:
             return self._pack_cache["val"]
@@ -292,6 +298,10 @@ class FeatureVolumeManager(CostVolumeManager):
             val = {n: torch.from_numpy(v).to(device) for n, v in packed.items()}
         raw = self._mlp_arrays(self.mlp)
         val["raw"] = [_f32c(a.to(device)) for a in raw]
+        if self.num_source_views <= self.MAX_FUSED_VIEWS and self.precision == "split16":
+            sp = mlp_pack.pack_mlp_split(*arrs, self.num_source_views)
+            for n in ("w1dyn", "w1pix", "w2"):
+                val["sp_" + n] = torch.from_numpy(sp[n].view(np.int16).copy()).to(device)
         if self._has_hint:
             h = [a.float().cpu().numpy() for a in self._mlp_arrays(self.hint_mlp)]
             val["hint"] = torch.from_numpy(mlp_pack.pack_hint_mlp(*h)).to(device)
@@ -351,7 +361,12 @@ class FeatureVolumeManager(CostVolumeManager):
         hook = FeatureVolumeManager._event_hook
         if hook is not None:
             hook("mlp_begin")
-        if _impl == "mfma":
+        if _impl == "mfma" and self.precision == "split16":
+            _abi.check(L.dt_cv_mlp_hint_split_f32(
+                _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(pk["sp_w1dyn"]), _abi.ptr(pk["sp_w1pix"]),
+                _abi.ptr(pk["sp_w2"]), _abi.ptr(pk["tail"]), _abi.ptr(hint_ptr), _abi.ptr(hd), _abi.ptr(hw_),
+                _abi.ptr(hm), H2, W2, _abi.ptr(vol), int(nhwc), b, k, h, w, D, stream), "dt_cv_mlp_hint_split_f32")
+        elif _impl == "mfma":
             _abi.check(L.dt_cv_mlp_hint_f32(
                 _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(pk["w1dyn"]), _abi.ptr(pk["w1pix"]),
                 _abi.ptr(pk["w2p"]), _abi.ptr(pk["tail"]), _abi.ptr(hint_ptr), _abi.ptr(hd), _abi.ptr(hw_),

@@ -209,3 +209,115 @@ def pack_head_mlp(Wa, ba, Wb, bb, Wc, bc):
                 tail[256 + h * 64 + blk * 16 + r] = wc[f]
     tail[384] = np.asarray(bc, np.float32).reshape(-1)[0]
     return dict(wa=wa.reshape(-1), wb=wb.reshape(-1), tail=tail)
+
+
+# ---- split-precision (fp16 hi/lo) packing for csrc/cv_mlp_split.hip ----------------------------------------------------------
+def split_dyn_columns(K):
+    """[K + ceil(K/2), 2, 8] column fed by (lane half kb, slot e) at every plane-dependent K16 step: K feature steps
+    (slot = warped channel 8*kb + e of view k), then one metadata step per view PAIR (slots 0..3: view 2m, 4..7: view 2m+1;
+    half 0: mask, dot*mask, ray.x, ray.z;  half 1: z', angle, ray.y, plane depth (view 0 only))."""
+    c = Columns(K)
+    tab = np.full((K + (K + 1) // 2, 2, 8), ZERO, dtype=np.int64)
+    for k in range(K):
+        for kb in range(2):
+            for e in range(8):
+                tab[k, kb, e] = c.warp + k * FEAT + 8 * kb + e
+        m, e0 = K + (k >> 1), 4 * (k & 1)
+        tab[m, 0, e0:e0 + 4] = (c.mask + k, c.dot + k, c.sray + 3 * k + 0, c.sray + 3 * k + 2)
+        tab[m, 1, e0:e0 + 4] = (c.z + k, c.ang + k, c.sray + 3 * k + 1, c.plane if k == 0 else ZERO)
+    return tab
+
+
+def split_pix_columns(K):
+    """Plane-independent K16 steps: step 0 = current features, then [ray.x, ray.y, ray.z, bias, pd_0, R_0, t_0, pd_1, ...]
+    sixteen per step (slot index n -> step 1 + n // 16, half (n % 16) // 8, e = n % 8)."""
+    c = Columns(K)
+    cols = [c.cray + 0, c.cray + 1, c.cray + 2, BIAS]
+    for k in range(K):
+        cols += [c.pd + k, c.R + k, c.t + k]
+    nsteps = 1 + (len(cols) + 15) // 16
+    tab = np.full((nsteps, 2, 8), ZERO, dtype=np.int64)
+    for kb in range(2):
+        for e in range(8):
+            tab[0, kb, e] = c.cur + 8 * kb + e
+    for n, col in enumerate(cols):
+        tab[1 + n // 16, (n % 16) // 8, n % 8] = col
+    return tab
+
+
+def split_w2_columns():
+    """Layer 2: step t = 2*block + q, slot (kb, e) = layer-1 accumulator register 8q + e of that block in lane half kb."""
+    tab = np.zeros((8, 2, 8), dtype=np.int64)
+    for t in range(8):
+        for kb in range(2):
+            for e in range(8):
+                tab[t, kb, e] = acc_feature(t >> 1, 8 * (t & 1) + e, kb)
+    return tab
+
+
+def _pack_split(W_ext, tab):
+    """W_ext [128, Cin + 2] (last two columns: zeros, bias); tab [S,2,8].  Returns uint16 [S, 2 parts, 4 blocks, 64 lanes, 8]:
+    the fp16 hi and lo parts of A[row i of block cb][slot (kb, e)], lane = kb*32 + i."""
+    cin = W_ext.shape[1] - 2
+    cols = np.where(tab == ZERO, cin, np.where(tab == BIAS, cin + 1, tab))
+    g = W_ext.T[cols]                                    # [S, kb, e, 128]
+    g = g.reshape(*cols.shape, 4, 32).transpose(0, 3, 1, 4, 2)  # [S, cb, kb, i, e]
+    g = np.ascontiguousarray(g, dtype=np.float32).reshape(cols.shape[0], 4, 64, 8)
+    hi = g.astype(np.float16)
+    lo = (g - hi.astype(np.float32)).astype(np.float16)
+    return np.ascontiguousarray(np.stack([hi, lo], 1)).view(np.uint16)
+
+
+def pack_mlp_split(W1, b1, W2, b2, W3, b3, K):
+    """dict(w1dyn, w1pix, w2: uint16 arrays of fp16 hi/lo weight fragments; tail: float32 as in pack_mlp)."""
+    base = pack_mlp(W1, b1, W2, b2, W3, b3, K)  # validates shapes; the tail (b2, W3, b3 in lane-register order) is shared
+    W1 = np.asarray(W1, dtype=np.float32)
+    W_ext = np.concatenate([W1, np.zeros((HID, 1), np.float32), np.asarray(b1, np.float32).reshape(HID, 1)], 1)
+    W2_ext = np.concatenate([np.asarray(W2, np.float32), np.zeros((HID, 2), np.float32)], 1)
+    return dict(w1dyn=_pack_split(W_ext, split_dyn_columns(K)).reshape(-1), w1pix=_pack_split(W_ext, split_pix_columns(K)).reshape(-1),
+                w2=_pack_split(W2_ext, split_w2_columns()).reshape(-1), tail=base["tail"])
+
+
+def emulate_split_mlp(packed, x_cols, K):
+    """CPU emulation of the split kernel's slot tables from the PACKED fp16 weights (hi + lo recombined in fp32; inputs kept
+    in fp32): proves on the CPU that the tables are a permutation of the reference MLP.  x_cols [N, Cin] -> score [N]."""
+    c = Columns(K)
+    N = x_cols.shape[0]
+    x_ext = np.concatenate([x_cols.astype(np.float32), np.zeros((N, 1), np.float32), np.ones((N, 1), np.float32)], 1)
+
+    def weights(buf, S):
+        w = buf.view(np.float16).astype(np.float32).reshape(S, 2, 4, 64, 8)
+        return w[:, 0] + w[:, 1]  # [S, cb, lane, e]
+
+    def run(buf, tab):
+        cols = np.where(tab == ZERO, c.total, np.where(tab == BIAS, c.total + 1, tab))
+        w = weights(buf, tab.shape[0])
+        acc = np.zeros((N, HID), np.float32)
+        for s in range(tab.shape[0]):
+            for kb in range(2):
+                for e in range(8):
+                    wv = w[s, :, kb * 32:(kb + 1) * 32, e].reshape(HID)  # [cb, i] -> feature 32*cb + i
+                    acc += x_ext[:, cols[s, kb, e]][:, None] * wv[None]
+        return acc
+
+    acc1 = run(packed["w1pix"], split_pix_columns(K)) + run(packed["w1dyn"], split_dyn_columns(K))
+    h1 = np.maximum(acc1, 0.01 * acc1)
+    tail = packed["tail"]
+    acc2 = np.zeros((N, HID), np.float32)
+    for h in range(2):
+        for blk in range(4):
+            for r in range(16):
+                acc2[:, acc_feature(blk, r, h)] = tail[h * 64 + blk * 16 + r]
+    w2 = weights(packed["w2"], 8)
+    tab2 = split_w2_columns()
+    for t in range(8):
+        for kb in range(2):
+            for e in range(8):
+                acc2 += h1[:, tab2[t, kb, e]][:, None] * w2[t, :, kb * 32:(kb + 1) * 32, e].reshape(HID)[None]
+    h2 = np.maximum(acc2, 0.01 * acc2)
+    s = np.zeros(N, np.float32)
+    for h in range(2):
+        for blk in range(4):
+            for r in range(16):
+                s += tail[128 + h * 64 + blk * 16 + r] * h2[:, acc_feature(blk, r, h)]
+    return s + tail[256]

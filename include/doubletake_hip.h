@@ -99,6 +99,18 @@ int dt_cv_mlp_hint_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc
                        const float* hint_mask_b1HW, int hint_h, int hint_w, float* volume,
                        int out_nhwc, int batch, int num_src, int h, int w, int num_planes,
                        dt_stream_t s);
+/* OPT-IN split-precision variant of dt_cv_mlp_hint_f32 (same reference functions, same arguments except the weights):
+ * the two dense contractions run on v_mfma_f32_32x32x16_f16 with every operand split into fp16 hi + lo parts
+ * (x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo, fp32 accumulation): fp32-class accuracy (dropped term 2^-22 relative) at 3/16
+ * of the fp32 matrix time.  Not the default anywhere.  Requires |inputs|, |weights|, |activations| < 65504.
+ * w1dyn/w1pix/w2: uint16 arrays of fp16 fragments from doubletake_amd.modules.mlp_pack.pack_mlp_split (sizes from
+ * dt_cv_mlp_split_pack_halves); tail: the same 260 floats as the fp32 kernel. */
+int dt_cv_mlp_split_pack_halves(int num_src, int* w1dyn, int* w1pix, int* w2);
+int dt_cv_mlp_hint_split_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc, const float* params,
+                             const uint16_t* w1dyn_h, const uint16_t* w1pix_h, const uint16_t* w2_h, const float* tail,
+                             const float* hint_mlp, const float* depth_hint, const float* hint_weights,
+                             const float* hint_mask, int hint_h, int hint_w, float* volume, int out_nhwc, int batch,
+                             int num_src, int h, int w, int num_planes, dt_stream_t s);
 
 /* Same function, one thread per (pixel, plane), plain fp32 FMAs, nn.Linear weight layouts
  * (W1 [128,Cin], b1, W2 [128,128], b2, W3 [1,128], b3).  GPU-side cross-check used by the

@@ -73,3 +73,20 @@ def test_head_pack_is_a_permutation(cin):
     y = nref.elu(nref.conv2d(y, p[2], p[3]))
     y = nref.conv2d(y, p[4], p[5])
     np.testing.assert_allclose(s, y.reshape(-1), atol=3e-6)
+
+
+@pytest.mark.parametrize("K", [1, 2, 7])
+def test_split_precision_pack_is_a_permutation(K):
+    """Slot tables of the opt-in fp16 hi/lo kernel (csrc/cv_mlp_split.hip): every reference column fed exactly once, and
+    the recombined hi + lo fragments reproduce the MLP to fp16-pair precision (weights carry 22 significant bits)."""
+    cin = syn.mlp_in_channels(K)
+    p = syn.formula_params(syn.mlp_param_shapes([cin, 128, 128, 1]), 5)
+    packed = mp.pack_mlp_split(*p, K)
+    assert packed["w1dyn"].dtype == np.uint16 and packed["w1dyn"].size == (K + (K + 1) // 2) * 2 * 4 * 64 * 8
+    x = syn.hash_normalish((64, cin), 3)
+    want = cref.mlp_forward(x, [(p[0], p[1]), (p[2], p[3]), (p[4], p[5])])[:, 0]
+    np.testing.assert_allclose(mp.emulate_split_mlp(packed, x, K), want, atol=2e-5)
+    cols = np.concatenate([mp.split_dyn_columns(K).reshape(-1), mp.split_pix_columns(K).reshape(-1)])
+    assert sorted(c for c in cols.tolist() if c >= 0) == list(range(cin))
+    assert (cols == mp.BIAS).sum() == 1
+    assert sorted(mp.split_w2_columns().reshape(-1).tolist()) == list(range(128))

@@ -299,3 +299,51 @@ def test_dot_volume_lds_vs_oracle_whole_tensor_cfg1():
     want, _ = ref.dot_cost_volume(inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_Ks"], inp["cur_invK"],
                                   inp["min_depth"], inp["max_depth"], D)
     np.testing.assert_allclose(vol.cpu().numpy(), want, atol=5e-4, rtol=0)
+
+
+# ---- opt-in split-precision MLP volume (csrc/cv_mlp_split.hip) ---------------------------------------------------------------
+@pytest.mark.parametrize("case", CASES)
+def test_split_precision_volume_vs_reference_golden(case):
+    """fp16 hi/lo operands on the fp16 matrix pipe, fp32 accumulation: its own parity budget (2e-4, the fp32 kernel's is
+    5e-5) against the SAME reference goldens, hint and no-hint managers."""
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import FeatureMeshHintVolumeManager, FeatureVolumeManager
+
+    g, inp, t, (b, k, h, w, D, seed) = _case(case)
+    m = FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    m.precision = "split16"
+    gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 11 + seed)
+    gu.load_formula_mlp(m.hint_mlp, [3, 12, 12, 1], 77 + seed)
+    vol, low, planes, mask = m(**gu.volume_call_args(t), cv_depth_hint_dict=gu.hint_dict(t), return_mask=True)
+    torch.cuda.synchronize()
+    err = np.abs(vol.cpu().numpy() - g["hint_volume"]).max()
+    assert err < 2e-4, f"split16 hint volume: max abs err {err}"
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["hint_mask_slow"])
+    m2 = FeatureVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    m2.precision = "split16"
+    gu.load_formula_mlp(m2.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 11 + seed)
+    vol2 = m2(**gu.volume_call_args(t))[0]
+    torch.cuda.synchronize()
+    assert np.abs(vol2.cpu().numpy() - g["mlp_volume"]).max() < 2e-4
+
+
+def test_split_precision_volume_fullsize_vs_fp32_kernel_and_reference_checksums():
+    """cfg2 (640x480, K=7, D=64): split16 against the exact-fp32 kernel on the whole tensor and against the reference's
+    full-size checksums."""
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import FeatureMeshHintVolumeManager
+
+    g = load_golden("volume_fullsize_checksums.npz")
+    b, k, h, w, D, seed = [int(v) for v in g["cfg2_meta"]]
+    inp = syn.volume_inputs(b, k, h, w, 16, seed)
+    t = gu.to_dev(inp)
+    m = FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 11 + seed)
+    gu.load_formula_mlp(m.hint_mlp, [3, 12, 12, 1], 77 + seed)
+    exact = m(**gu.volume_call_args(t), cv_depth_hint_dict=gu.hint_dict(t))[0]
+    m.precision = "split16"
+    split = m(**gu.volume_call_args(t), cv_depth_hint_dict=gu.hint_dict(t))[0]
+    torch.cuda.synchronize()
+    d = (exact - split).abs()
+    assert d.max().item() < 2e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+    _probe_check(split.contiguous().cpu().numpy(), "cfg2_hint", g, 2e-4)
