@@ -249,6 +249,9 @@ def main():
     ap.add_argument("--cpu-threads", default="8,all", help="thread counts of the cpu_baseline leg ('all' = physical cores)")
     ap.add_argument("--cpu-batched", action="store_true", help="also time the batched (Fast-manager) CPU volume once")
     ap.add_argument("--no-fuse", action="store_true", help="skip the TSDF integration of the gathered frames")
+    ap.add_argument("--mlp-precision", choices=("fp32", "split16"), default="fp32",
+                    help="arithmetic of the matching-MLP contractions in the volume kernel: exact fp32 MFMA (default, the headline) "
+                         "or the opt-in split-precision mode (fp16 hi/lo operands on the fp16 matrix pipe, fp32 accumulation)")
     ap.add_argument("--streams", type=int, default=2,
                     help="run consecutive keyframes on this many HIP streams (frames are independent in this workload; the "
                          "TSDF integrations stay in frame order)")
@@ -295,6 +298,7 @@ def main():
     _abi.lib()
     inp, pyr, t, pyr_t = build_inputs(device, seed=1000 + rank)
     model = build_model(device)
+    model.cost_volume.precision = args.mlp_precision
     hint = {n: t[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
     fuser = None
     if not args.no_fuse:
@@ -479,7 +483,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.mlp_precision == "fp32" else "f32 (opt-in: MLP products as split fp16 hi/lo pairs, f32 accumulate)",
             "data": "synthetic",
             "config": {
                 "workload": "DoubleTake-small hot path: mesh-hint cost volume + CVEncoder + SkipDecoderRegression, "
@@ -491,7 +495,8 @@ def main():
                 "parallelism": f"keyframe-shard x{world}" + ("" if args.no_fuse else " + all_gather(depth,K,pose) + replica TSDF integrate"),
             },
             "roofline": {
-                "kernel": "cv_mlp_mfma_kernel (fused warp + metadata + matching MLP + hint MLP)",
+                "kernel": "cv_mlp_mfma_kernel (fused warp + metadata + matching MLP + hint MLP)" if args.mlp_precision == "fp32"
+                          else "cv_mlp_split_kernel (same function, split-fp16 products; fraction still quoted against the fp32 MFMA peak)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS,

@@ -35,6 +35,10 @@ namespace sp {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifndef DT_SPLIT_RTZ
+#define DT_SPLIT_RTZ 1  // operand split by truncation (3 VALU per value) instead of round-to-nearest (4)
+#endif
+
 constexpr int kF = 16;
 constexpr int kFragHalves = 64 * 8;         // one A fragment: 64 lanes x 8 halves = 1 KB
 constexpr int kStepHalves = 2 * 4 * kFragHalves;  // [part hi|lo][4 output blocks]
@@ -129,12 +133,14 @@ __device__ __forceinline__ float hint_mlp_eval_lds(const float* hm, float s, flo
   return part + __shfl_xor(part, 32, 64) + hm[216];
 }
 
-// x[0..7] (fp32) -> hi / lo fp16 operands.  hi = x truncated to 11 significant bits (v_cvt_pkrtz_f16_f32), whose fp32
-// value is x with the low 13 mantissa bits cleared, so x - hi is exact and fits fp16 after one more truncation.
+// x[0..7] (fp32) -> hi / lo fp16 operands: hi = fp16(x), lo = fp16(x - hi) (the difference is exact in fp32).
 struct SplitB {
   half8 hi, lo;
 };
 __device__ __forceinline__ SplitB split8(const float (&x)[8]) {
+#if DT_SPLIT_RTZ
+  // hi = x truncated to 11 significant bits (one v_cvt_pkrtz_f16_f32 per pair); its fp32 value is x with the low 13
+  // mantissa bits cleared (one v_and), so the remainder costs one v_sub and is exact: 3 instructions per value
   union {
     half8 v;
     decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) p[4];
@@ -151,18 +157,33 @@ __device__ __forceinline__ SplitB split8(const float (&x)[8]) {
   s.hi = H.v;
   s.lo = L.v;
   return s;
+#else
+  SplitB s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 hi = (_Float16)x[i];          // round to nearest: |x - hi| <= 2^-11 |x|
+    s.hi[i] = hi;
+    s.lo[i] = (_Float16)(x[i] - (float)hi);      // exact difference, rounded once
+  }
+  return s;
+#endif
 }
 
-// acc[cb] += W[cb] * x for the four 32-feature output blocks of one K16 step: three MFMAs per block
+// Issue order: the three partial products of one output block are dependent MFMAs (same accumulator, ~50-cycle latency),
+// so the loop nest is part-major: four independent chains in flight at any time.
 #define DT_SPLIT_STEP(ACC, WSTEP, B)                                                                              \
   do {                                                                                                            \
+    half8 ah_[4], al_[4];                                                                                         \
     _Pragma("unroll") for (int cb_ = 0; cb_ < 4; ++cb_) {                                                         \
-      const half8 ah_ = *reinterpret_cast<const half8*>((WSTEP) + (0 * 4 + cb_) * kFragHalves + lane * 8);        \
-      const half8 al_ = *reinterpret_cast<const half8*>((WSTEP) + (1 * 4 + cb_) * kFragHalves + lane * 8);        \
-      ACC[cb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, (B).hi, ACC[cb_], 0, 0, 0);                          \
-      ACC[cb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, (B).lo, ACC[cb_], 0, 0, 0);                          \
-      ACC[cb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, (B).hi, ACC[cb_], 0, 0, 0);                          \
+      ah_[cb_] = *reinterpret_cast<const half8*>((WSTEP) + (0 * 4 + cb_) * kFragHalves + lane * 8);                \
+      al_[cb_] = *reinterpret_cast<const half8*>((WSTEP) + (1 * 4 + cb_) * kFragHalves + lane * 8);                \
     }                                                                                                             \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < 4; ++cb_)                                                           \
+      ACC[cb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_[cb_], (B).hi, ACC[cb_], 0, 0, 0);                     \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < 4; ++cb_)                                                           \
+      ACC[cb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_[cb_], (B).lo, ACC[cb_], 0, 0, 0);                     \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < 4; ++cb_)                                                           \
+      ACC[cb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_[cb_], (B).hi, ACC[cb_], 0, 0, 0);                     \
   } while (0)
 
 template <bool HINT>
@@ -346,27 +367,32 @@ __global__ __launch_bounds__(512, 2) void cv_mlp_split_kernel(const Args a) {
           h1[i * 2 + q] = split8(t8);
         }
 
-      // ---- layer 2 in four passes of 32 output features, layer 3 on the VALU ------------------------------------------
+      // ---- layer 2 in four passes of 32 output features; inside a pass the main (hi*hi) and the correction (lo*hi + hi*lo)
+      //      products accumulate in two separate registers sets = two independent MFMA chains (a dependent 32x32x16 MFMA
+      //      waits ~50 cycles, an independent one issues every ~40), summed before the activation.  Layer 3 on the VALU.
       float s = 0.f;
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
-        f32x16 acc2;
+        f32x16 accm, accc;
         const float* bl = lds_tail + half * 64 + pass * 16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = bl[r];
+        for (int r = 0; r < 16; ++r) {
+          accm[r] = bl[r];
+          accc[r] = 0.f;
+        }
 #pragma unroll
         for (int t = 0; t < kW2Steps; ++t) {
           const _Float16* ws = lds_w2 + (size_t)t * kStepHalves;
           const half8 ah = *reinterpret_cast<const half8*>(ws + (0 * 4 + pass) * kFragHalves + lane * 8);
           const half8 al = *reinterpret_cast<const half8*>(ws + (1 * 4 + pass) * kFragHalves + lane * 8);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, h1[t].hi, acc2, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, h1[t].lo, acc2, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, h1[t].hi, acc2, 0, 0, 0);
+          accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, h1[t].hi, accm, 0, 0, 0);
+          accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, h1[t].hi, accc, 0, 0, 0);
+          accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, h1[t].lo, accc, 0, 0, 0);
         }
         const float* w3 = lds_tail + 128 + half * 64 + pass * 16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v2 = acc2[r];
+          const float v2 = accm[r] + accc[r];
           s += w3[r] * fmaxf(v2, 0.01f * v2);
         }
       }

@@ -16,7 +16,10 @@ from doubletake_amd.utils import synthetic as syn
 
 def main():
     out = {}
-    for name, (b, k, h, w, D) in {"cfg2": (1, 7, 120, 160, 64), "cfg3_b8": (8, 7, 96, 128, 64)}.items():
+    cfgs = {"cfg2": (1, 7, 120, 160, 64), "cfg3_b8": (8, 7, 96, 128, 64)}
+    if "--once" in sys.argv:
+        cfgs = {"cfg2": cfgs["cfg2"]}
+    for name, (b, k, h, w, D) in cfgs.items():
         t = gu.to_dev(syn.volume_inputs(b, k, h, w, 16, 1000))
         m = cvmod.FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
         gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 31)
@@ -36,7 +39,7 @@ def main():
             for _ in range(3):
                 vols[prec] = call()[0]
             cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
-            for _ in range(20):
+            for _ in range(2 if "--once" in sys.argv else 20):
                 call()
             torch.cuda.synchronize()
             cvmod.FeatureVolumeManager._event_hook = None

@@ -102,3 +102,20 @@ def test_volume_and_encoder_features_against_reference_fullsize_checksums(name):
     feats = model.cost_volume_net(vol, pyr[1:])
     for i, f in enumerate(feats):
         _check(g, name, f"cv_feat{i}", f.contiguous().cpu().numpy(), 2e-4)
+
+
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_full_b8"])
+def test_whole_model_split_precision_mode_within_depth_tolerance(name):
+    """Opt-in split-precision volume kernel (manager.precision = "split16") inside the whole model, against the same
+    reference full-size checksums and the same 1e-3 depth tolerance as the exact-fp32 path."""
+    import gpu_util as gu
+
+    g = load_golden("model_fullsize_checksums.npz")
+    model, inp, t, pyr = build_case(name)
+    model.cost_volume.precision = "split16"
+    out = model.forward_from_features(pyr, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"], t["src_Ks"],
+                                      t["cur_invK"], gu.hint_dict(t), return_mask=True)
+    torch.cuda.synchronize()
+    for i in range(4):
+        _check(g, name, f"depth_pred_s{i}_b1hw", out[f"depth_pred_s{i}_b1hw"].cpu().numpy(), 1e-3)
+        _check(g, name, f"log_depth_pred_s{i}_b1hw", out[f"log_depth_pred_s{i}_b1hw"].cpu().numpy(), 5e-4)
