@@ -65,6 +65,8 @@ SIGNATURES = {
     "dt_conv1x1_head_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "dt_head_mlp_pack_floats": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "dt_head_mlp_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "dt_head_mlp_multi_f32": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                                   C.POINTER(_P), C.POINTER(_L), C.POINTER(_I), _P]),
     "dt_upsample2x_bilinear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dt_exp_f32": (_I, [_P, _P, _L, _P]),
     "dt_stem_im2col_f32": (_I, [_P, _P, _I, _I, _I, _P]),

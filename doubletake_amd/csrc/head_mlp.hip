@@ -142,19 +142,17 @@ __global__ __launch_bounds__(256, 1) void head_mlp_kernel(const HeadArgs a) {
 // owns ONE tile and its four waves split the 128 hidden features (wave w = feature block w): 4x shorter
 // chains, 4x more workgroups, weights read straight from L2 (each wave only needs its quarter).
 template <int NG>
-__global__ __launch_bounds__(256) void head_mlp_split_kernel(const HeadArgs a) {
-  __shared__ float hbuf[4 * 16 * 64];
-  __shared__ float red[4 * 32];
+__device__ __forceinline__ void head_split_body(const HeadArgs& a, const unsigned tile, float* hbuf, float* red) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, p = lane & 31;
   const int lane_off = (half * 32 + p) * 4 + wave;  // this wave's component of the packed float4
-  const long pix = (long)blockIdx.x * 32 + p;
+  const long pix = (long)tile * 32 + p;
   const long pc = pix < a.pixels ? pix : a.pixels - 1;
 
   float4 xq[NG];
   {
-    const float4* src = reinterpret_cast<const float4*>(a.in + pc * a.cin + half * 4);
+    const float4* src = reinterpret_cast<const float4*>(a.in + pc * (NG * 8) + half * 4);
 #pragma unroll
     for (int g = 0; g < NG; ++g) xq[g] = src[g * 2];
   }
@@ -200,7 +198,43 @@ __global__ __launch_bounds__(256) void head_mlp_split_kernel(const HeadArgs a) {
   }
 }
 
+template <int NG>
+__global__ __launch_bounds__(256) void head_mlp_split_kernel(const HeadArgs a) {
+  __shared__ float hbuf[4 * 16 * 64];
+  __shared__ float red[4 * 32];
+  head_split_body<NG>(a, blockIdx.x, hbuf, red);
+}
+
+// The three coarse heads of one decoder pass (s3: 256 ch, s2: 128 ch, s1: 64 ch at 640x480) are independent and
+// each far too small to fill the chip (38 / 150 / 600 tiles): ONE grid runs all of them, every workgroup picking
+// its head from the tile prefix.  Same body as head_mlp_split_kernel, so the results are bit-identical to separate
+// launches; what goes away is two launch boundaries and two latency-bound tails.
+constexpr int kHeadMultiMax = 4;
+struct HeadMultiArgs {
+  HeadArgs h[kHeadMultiMax];
+  unsigned first[kHeadMultiMax + 1];  // tile prefix: head i owns virtual blocks [first[i], first[i+1])
+};
+
+__global__ __launch_bounds__(256) void head_mlp_multi_kernel(const HeadMultiArgs m) {
+  __shared__ float hbuf[4 * 16 * 64];
+  __shared__ float red[4 * 32];
+  const unsigned b = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < kHeadMultiMax; ++k) i += (b >= m.first[k]) ? 1 : 0;
+  const HeadArgs& a = m.h[i];
+  const unsigned tile = b - m.first[i];
+  const int cin = a.cin;
+  if (cin == 256)
+    head_split_body<32>(a, tile, hbuf, red);
+  else if (cin == 128)
+    head_split_body<16>(a, tile, hbuf, red);
+  else
+    head_split_body<8>(a, tile, hbuf, red);
+}
+
 static int g_head_cus = 0;
+constexpr long kHeadSplitMaxTiles = 1024;
 
 }  // namespace dt
 
@@ -232,7 +266,7 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
   HeadArgs a;
   a.in = in_nhwc; a.wa = wa; a.wb = wb; a.tail = tail; a.out = out; a.out_exp = out_exp; a.pixels = pixels; a.cin = cin;
   const long tiles = (pixels + 31) / 32;
-  static const long split_max_tiles = [] { const char* e = getenv("DT_HEAD_SPLIT_MAX_TILES"); return e ? atol(e) : 1024L; }();
+  static const long split_max_tiles = [] { const char* e = getenv("DT_HEAD_SPLIT_MAX_TILES"); return e ? atol(e) : kHeadSplitMaxTiles; }();
   if (tiles <= split_max_tiles) {  // small image: one tile per workgroup, hidden features split over the waves
     if (cin == 64)
       hipLaunchKernelGGL(head_mlp_split_kernel<8>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
@@ -259,6 +293,32 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
   if (cin == 64) DT_LAUNCH_HEAD(8); else DT_LAUNCH_HEAD(16);
 #undef DT_LAUNCH_HEAD
   return check_launch("dt_head_mlp_f32");
+}
+
+int dt_head_mlp_multi_f32(int n_heads, const float* const* in_nhwc, const float* const* wa, const float* const* wb,
+                          const float* const* tail, float* const* out, float* const* out_exp, const int64_t* pixels,
+                          const int* cin, dt_stream_t s) {
+  DT_REQUIRE(n_heads >= 1 && n_heads <= kHeadMultiMax, "dt_head_mlp_multi_f32: n_heads=%d (1..%d)", n_heads, kHeadMultiMax);
+  DT_REQUIRE(in_nhwc && wa && wb && tail && out && pixels && cin, "dt_head_mlp_multi_f32: null pointer table");
+  HeadMultiArgs m;
+  unsigned total = 0;
+  for (int i = 0; i < kHeadMultiMax; ++i) {
+    const int j = i < n_heads ? i : n_heads - 1;  // unused slots repeat the last head and own no blocks
+    DT_REQUIRE(in_nhwc[j] && wa[j] && wb[j] && tail[j] && out[j], "dt_head_mlp_multi_f32: null pointer in head %d", j);
+    DT_REQUIRE(cin[j] == 64 || cin[j] == 128 || cin[j] == 256, "dt_head_mlp_multi_f32: head %d cin=%d (64, 128 or 256 supported)", j, cin[j]);
+    const long tiles = ((long)pixels[j] + 31) / 32;
+    DT_REQUIRE(pixels[j] > 0 && tiles <= kHeadSplitMaxTiles, "dt_head_mlp_multi_f32: head %d has %ld pixels (1..%ld supported; use dt_head_mlp_f32)",
+               j, (long)pixels[j], kHeadSplitMaxTiles * 32);
+    HeadArgs& a = m.h[i];
+    a.in = in_nhwc[j]; a.wa = wa[j]; a.wb = wb[j]; a.tail = tail[j]; a.out = out[j]; a.out_exp = out_exp ? out_exp[j] : nullptr;
+    a.pixels = pixels[j]; a.cin = cin[j];
+    m.first[i] = total;
+    if (i < n_heads) total += (unsigned)tiles;
+  }
+  m.first[kHeadMultiMax] = total;
+  for (int i = n_heads; i < kHeadMultiMax; ++i) m.first[i] = 0xffffffffu;  // never selected
+  hipLaunchKernelGGL(head_mlp_multi_kernel, dim3(total), dim3(256), 0, to_stream(s), m);
+  return check_launch("dt_head_mlp_multi_f32");
 }
 
 }  // extern "C"

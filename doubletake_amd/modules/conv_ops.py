@@ -244,15 +244,10 @@ def conv1x1_head(x, conv: nn.Conv2d, with_exp=False):
     return (out, out_e) if with_exp else out
 
 
-def head_mlp(x, head: nn.Sequential, with_exp=False):
-    """Fused 1x1 -> ELU -> 1x1 -> ELU -> 1x1 regression head (modules/networks_fast.py:102-132).
-    x NHWC [n,c,h,w] (c = 64, 128, or 256 for small maps) -> [n,1,h,w]; with_exp: (out, exp(out)) from the same launch."""
+def _head_pack(head: nn.Sequential, dev):
     from . import mlp_pack
 
-    L = _abi.lib()
     ca, cb_, cc = head[0], head[2], head[4]
-    n, c, h, w = x.shape
-    dev = x.device
     params = [ca.weight, ca.bias, cb_.weight, cb_.bias, cc.weight, cc.bias]
     key = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
     hit = head.__dict__.get("_dt_head_pack")
@@ -261,7 +256,38 @@ def head_mlp(x, head: nn.Sequential, with_exp=False):
         pk = mlp_pack.pack_head_mlp(*arrs)
         hit = (key, {k: torch.from_numpy(v).to(dev) for k, v in pk.items()})
         head.__dict__["_dt_head_pack"] = hit
-    pk = hit[1]
+    return hit[1]
+
+
+HEAD_MULTI_MAX_PIXELS = 32 * 1024  # per map; larger maps take the persistent kernel of dt_head_mlp_f32
+HEAD_MULTI_LAUNCH = _os.environ.get("DT_HEAD_MULTI", "1") != "0"
+
+
+def head_mlp_multi(xs, heads, with_exp=False):
+    """head_mlp for 2-4 independent small feature maps (the coarse decoder scales) in ONE launch; returns a list
+    like [head_mlp(x, h, with_exp) for x, h in zip(xs, heads)], bit-identical to it."""
+    L = _abi.lib()
+    n_h = len(xs)
+    dev = xs[0].device
+    pks = [_head_pack(h, dev) for h in heads]
+    outs = [torch.empty((x.shape[0], 1, x.shape[2], x.shape[3]), device=dev, dtype=torch.float32) for x in xs]
+    outs_e = [torch.empty_like(o) for o in outs] if with_exp else [None] * n_h
+    tab = lambda vals: (C.c_void_p * n_h)(*[_abi.ptr(v) for v in vals])
+    pixels = (C.c_int64 * n_h)(*[x.shape[0] * x.shape[2] * x.shape[3] for x in xs])
+    cin = (C.c_int * n_h)(*[x.shape[1] for x in xs])
+    _abi.check(L.dt_head_mlp_multi_f32(n_h, tab(xs), tab([p["wa"] for p in pks]), tab([p["wb"] for p in pks]),
+                                       tab([p["tail"] for p in pks]), tab(outs), tab(outs_e), pixels, cin,
+                                       _abi.current_stream(dev)), "dt_head_mlp_multi_f32")
+    return [(o, e) for o, e in zip(outs, outs_e)] if with_exp else outs
+
+
+def head_mlp(x, head: nn.Sequential, with_exp=False):
+    """Fused 1x1 -> ELU -> 1x1 -> ELU -> 1x1 regression head (modules/networks_fast.py:102-132).
+    x NHWC [n,c,h,w] (c = 64, 128, or 256 for small maps) -> [n,1,h,w]; with_exp: (out, exp(out)) from the same launch."""
+    L = _abi.lib()
+    n, c, h, w = x.shape
+    dev = x.device
+    pk = _head_pack(head, dev)
     out = torch.empty((n, 1, h, w), device=dev, dtype=torch.float32)
     out_e = torch.empty_like(out) if with_exp else None
     _abi.check(L.dt_head_mlp_f32(_abi.ptr(x), _abi.ptr(pk["wa"]), _abi.ptr(pk["wb"]), _abi.ptr(pk["tail"]), _abi.ptr(out),

@@ -84,10 +84,21 @@ class SkipDecoderRegression(SkipDecoder):
         DepthModelCVHint): the head kernels also write depth_pred_s{i}_b1hw = exp(log depth), saving the four
         exp passes of experiment_modules/doubletake_model.py:410-418."""
         out = self._features(features, impl=_impl)
+        todo = []
         for oi, scale in ((1, 3), (2, 2), (3, 1), (4, 0)):
             head = getattr(self, f"out{oi}")
             feat = out[f"feature_s{scale}_b1hw"]
-            if _impl == "mfma" and ops.head_mlp_supported(feat, head):
+            todo.append((scale, feat, head, _impl == "mfma" and ops.head_mlp_supported(feat, head)))
+        # the coarse heads are independent and each far too small to fill the chip: one launch for all of them
+        small = [t for t in todo if t[3] and t[1].shape[0] * t[1].shape[2] * t[1].shape[3] <= ops.HEAD_MULTI_MAX_PIXELS]
+        results = {}
+        if ops.HEAD_MULTI_LAUNCH and len(small) >= 2:
+            for t, res in zip(small, ops.head_mlp_multi([t[1] for t in small], [t[2] for t in small], with_exp=with_depth)):
+                results[t[0]] = res
+        for scale, feat, head, fused in todo:
+            if scale in results:
+                res = results[scale]
+            elif fused:
                 # 64- and 128-channel heads (scales 0-2, 99 % of the pixels): one fused kernel
                 res = ops.head_mlp(feat, head, with_exp=with_depth)
             else:

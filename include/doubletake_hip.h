@@ -204,6 +204,13 @@ int dt_conv1x1_head_f32(const float* in_nhwc, const float* w_c, const float* bia
 int dt_head_mlp_pack_floats(int cin, int* wa, int* wb, int* tail);
 int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, const float* tail,
                     float* out, float* out_exp, int64_t pixels, int cin, dt_stream_t s);
+/* The same head for up to 4 independent feature maps (the coarse scales of one decoder pass,
+ * modules/networks_fast.py:134-141 loops over them) in ONE launch.  Host-side tables of n_heads device
+ * pointers / sizes; every map at most 32768 pixels; out_exp (table or entries) may be NULL.  Results are
+ * bit-identical to n_heads calls of dt_head_mlp_f32. */
+int dt_head_mlp_multi_f32(int n_heads, const float* const* in_nhwc, const float* const* wa,
+                          const float* const* wb, const float* const* tail, float* const* out,
+                          float* const* out_exp, const int64_t* pixels, const int* cin, dt_stream_t s);
 /* bilinear x2 upsample, align_corners=False (utils/generic_utils.py:95-104), NHWC. */
 int dt_upsample2x_bilinear_f32(const float* in_nhwc, float* out_nhwc, int n, int h, int w,
                                int c, dt_stream_t s);

@@ -184,6 +184,35 @@ def test_small_model_graph_full_size_mfma_vs_simple():
     assert tuple(a["log_depth_pred_s0_b1hw"].shape) == (1, 1, 2 * h, 2 * w)
 
 
+@pytest.mark.parametrize("with_exp", [False, True])
+def test_coarse_heads_one_launch_is_bit_identical(with_exp):
+    """dt_head_mlp_multi_f32 (the three coarse regression heads of one decoder pass in ONE grid) against three
+    dt_head_mlp_f32 launches: same body, so every output must be bit-equal; includes a ragged last tile."""
+    import gpu_util as gu
+    from doubletake_amd.modules import conv_ops as ops
+
+    shapes = [(256, 30, 40), (128, 60, 80), (64, 120, 160), (64, 7, 9)]
+    heads, xs = [], []
+    for i, (c, h, w) in enumerate(shapes):
+        head = torch.nn.Sequential(torch.nn.Conv2d(c, 128, 1), torch.nn.ELU(), torch.nn.Conv2d(128, 128, 1), torch.nn.ELU(),
+                                   torch.nn.Conv2d(128, 1, 1)).to(gu.dev())
+        gu.set_formula_weights(head, 40 + i)
+        heads.append(head)
+        xs.append(ops.as_nhwc(_t(syn.hash_normalish((1, c, h, w), 50 + i))))
+    for n in (2, 3, 4):
+        got = ops.head_mlp_multi(xs[:n], heads[:n], with_exp=with_exp)
+        for x, head, g in zip(xs[:n], heads[:n], got):
+            want = ops.head_mlp(x, head, with_exp=with_exp)
+            if with_exp:
+                assert torch.equal(g[0], want[0]) and torch.equal(g[1], want[1])
+            else:
+                assert torch.equal(g, want)
+    # a map beyond the one-tile-per-workgroup limit is refused, not silently truncated
+    big = ops.as_nhwc(torch.zeros((1, 64, 240, 320), device=gu.dev()))
+    with pytest.raises(RuntimeError, match="dt_head_mlp_multi_f32"):
+        ops.head_mlp_multi([xs[2], big], [heads[2], heads[3]])
+
+
 def test_full_model_graph_full_size_mfma_vs_simple():
     """DoubleTake full model decoder (DepthDecoderPP, EfficientNetV2-S widths) at 120x160 / D=64."""
     import gpu_util as gu
