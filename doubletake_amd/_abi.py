@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
     """struct dt_conv_desc (include/doubletake_hip.h)."""
     _fields_ = [("n", C.c_int), ("h_out", C.c_int), ("w_out", C.c_int), ("c_out", C.c_int), ("nsrc", C.c_int),
                 ("c", C.c_int * 3), ("up", C.c_int * 3), ("ksize", C.c_int), ("stride", C.c_int), ("act", C.c_int),
-                ("h_in", C.c_int), ("w_in", C.c_int), ("pad_mode", C.c_int)]
+                ("h_in", C.c_int), ("w_in", C.c_int), ("pad_mode", C.c_int), ("transposed", C.c_int)]
 
 
 class TsdfThresholds(C.Structure):
@@ -57,6 +57,7 @@ SIGNATURES = {
     "dt_conv_pack_floats": (_L, [_I, _I, _I]),
     "dt_conv_pack_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "dt_conv2d_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dt_conv_transposed_tiling": (_I, [C.POINTER(ConvDesc)]),
     "dt_conv_wino_pack_floats": (_L, [_I, _I]),
     "dt_conv_wino_pack_f32": (_I, [_P, _P, _I, _I, _P]),
     "dt_conv2d_wino_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),

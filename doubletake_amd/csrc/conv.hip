@@ -16,6 +16,12 @@
 // encoder yields >= 4 waves per MFMA block and the grid stays fine-grained enough to balance
 // 1024 SIMDs.  Bias, residual add, LeakyReLU/ELU, channel concat of up to three sources and
 // nearest x2 upsampling of a source are fused (never materialised).
+#include <array>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "common.hpp"
 
 namespace dt {
@@ -37,7 +43,34 @@ struct ConvArgs {
   int cb_major;       // 1: channel block is the slowest block coordinate (weight-dominated layers)
   int groups;  // total 8-channel input groups over all sources
   int tiles_x, tiles_y, co_blocks;
+  // K-split kernels only:
+  int tr;             // 1: the image is tiled in the transposed frame (h/w fields hold the swapped extents, the weights
+                      //    are packed with swapped taps): tall 8x4 instead of 4x8 output patches, same results
+  int kparts;         // P > 1: P workgroups share one output block, each with 1/P of the K groups; the last to arrive sums
+                      //    the partial blocks in part order (deterministic) and runs the epilogue
+  int kplain;         // the first kplain blocks keep ONE workgroup each (launched first); only the remaining blocks are split:
+                      //    with a few blocks more than CUs, the leftovers become many small workgroups that fill the second round
+  float* part_buf;    // [blocks - kplain][P][4 waves][64 lanes] float4 partial blocks
+  unsigned* part_cnt; // [blocks - kplain] arrival counters, zero between launches
+#ifdef DT_CONV_TIMING
+  unsigned long long* timing;
+#endif
 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Hand-off of a partial output block between workgroups of ONE launch.  The per-CU L1 is never refreshed by other CUs'
+// stores and the per-XCD L2s are not coherent with each other, so the payload travels write-through / cache-bypassing
+// (sc0 sc1 on both sides) and is ordered against the arrival counter by draining vmcnt, not by cache-wide fences
+// (an agent-scope release writes back the whole XCD L2: microseconds per workgroup).
+__device__ __forceinline__ void store_f4_coherent(float4* p, float4 v) {
+  const f32x4 x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ float4 load_f4_coherent(const float4* p) {
+  f32x4 x;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
+  return make_float4(x[0], x[1], x[2], x[3]);
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == DT_ACT_LRELU02) return v >= 0.f ? v : 0.2f * v;
@@ -59,10 +92,12 @@ __device__ __forceinline__ long xcd_contiguous_block(int xcd_remap, unsigned b, 
 // element offset of input pixel (iy, ix) of image n inside one NHWC source (nearest-upsampled when
 // `up`), plus this lane's 4-channel half of the 8-channel group; -1 = zero padding
 __device__ __forceinline__ int pixel_offset(bool inside, int n, int iy, int ix, int h_in, int w_in, int up, int cs,
-                                            int lane) {
+                                            int lane, int tr = 0) {
   const int hs = up ? (h_in >> 1) : h_in, ws = up ? (w_in >> 1) : w_in;
   const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
-  return inside ? ((n * hs + sy) * ws + sx) * cs + (lane & 1) * 4 : -1;
+  // tr: (iy, ix) are coordinates of the transposed frame, i.e. the real pixel is (row ix, column iy) of a ws x hs image
+  const int pix = tr ? (n * ws + sx) * hs + sy : (n * hs + sy) * ws + sx;
+  return inside ? pix * cs + (lane & 1) * 4 : -1;
 }
 
 // SPLIT = number of waves that share one 32-channel x 32-pixel output block by splitting K:
@@ -83,6 +118,17 @@ struct ConvMfmaCfg {
   static constexpr int THREADS = NW * 64;
 };
 
+// -DDT_CONV_TIMING: wave 0 of every workgroup of the K-split kernels records s_memrealtime (100 MHz) at its phase
+// boundaries into the buffer whose address the host reads from the environment (scripts/conv_phase_timing.py).
+#ifdef DT_CONV_TIMING
+#define DT_STAMP(SLOT)                                                                              \
+  do {                                                                                              \
+    if (a.timing && threadIdx.x == 0) a.timing[(size_t)vblock * 24 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define DT_STAMP(SLOT) do { } while (0)
+#endif
+
 // The body takes a VIRTUAL block index / grid size so that two convolutions can share one launch (conv_pair_kernel).
 template <int KS, int ST, int SPLIT>
 __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restrict__ lds, unsigned vblock, unsigned vgrid) {
@@ -95,6 +141,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
   constexpr int PAD = KS / 2;
   constexpr int TAPS = KS * KS;
 
+  DT_STAMP(0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, p = lane & 31;
@@ -111,7 +158,18 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
   auto lds_off = [&](int hf, int row, int col) { return SWZ ? ((hf * IH + row) * PITCH + col) * 4 : (row * IW + col) * 8 + hf * 4; };
 
   const long total_blocks = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
-  long bid = (SPLIT == 1) ? (long)vblock * 4 + wave : xcd_contiguous_block(a.xcd_remap, vblock, vgrid);
+  // cross-workgroup K split: workgroups [0, kplain) own a whole block each, the others share the remaining blocks P ways;
+  // the parts of a block are neighbours in the logical order (same XCD, shared input patch in L2)
+  const bool split_wg = (SPLIT != 1) && a.kparts > 1 && vblock >= (unsigned)a.kplain;
+  const int kparts = split_wg ? a.kparts : 1;
+  long bid;
+  if (SPLIT == 1) bid = (long)vblock * 4 + wave;
+  else if (a.kparts <= 1) bid = xcd_contiguous_block(a.xcd_remap, vblock, vgrid);
+  else if (!split_wg) bid = xcd_contiguous_block(a.xcd_remap, vblock, (unsigned)a.kplain);
+  else bid = xcd_contiguous_block(a.xcd_remap, vblock - (unsigned)a.kplain, vgrid - (unsigned)a.kplain);
+  const int part = split_wg ? (int)(bid % kparts) : 0;
+  if (split_wg) bid = a.kplain + bid / kparts;
+  const long blk = bid - a.kplain;  // index into the partial-block scratch
   const bool have_block = bid < total_blocks;
   if (!have_block) bid = total_blocks - 1;  // keep the wave alive (no barriers are skipped); it stores nothing
   int cb;
@@ -132,6 +190,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
 
   const int oy = ty * kPH + py, ox = tx * kPW + px;
   const int iy0 = ty * kPH * ST - PAD, ix0 = tx * kPW * ST - PAD;
+  const int tr = (SPLIT == 1) ? 0 : a.tr;
   float* tile = lds + wave * TILE_FLOATS;
 
   // one accumulator chain per wave is enough: dependent v_mfma_f32_32x32x2_f32 issue back to back
@@ -141,8 +200,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
-  const int g_first = (SPLIT == 1) ? 0 : wave;
-  const int g_step = (SPLIT == 1) ? 1 : SPLIT;
+  const int g_first = (SPLIT == 1) ? 0 : part * SPLIT + wave;
+  const int g_step = (SPLIT == 1) ? 1 : SPLIT * kparts;
 
   // ---- per-lane, group-invariant addressing (hoisted out of the K loop) ----------------------------
   // element offset of each staged pixel inside each source (or -1: zero padding / outside the patch)
@@ -158,9 +217,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
       ix = min(max(ix, 0), a.w_in - 1);
       inside = idx < NPIX;
     }
-    poff0[it] = pixel_offset(inside, n, iy, ix, a.h_in, a.w_in, a.up[0], a.c[0], lane);
-    poff1[it] = pixel_offset(inside && a.nsrc > 1, n, iy, ix, a.h_in, a.w_in, a.up[1], a.c[1], lane);
-    poff2[it] = pixel_offset(inside && a.nsrc > 2, n, iy, ix, a.h_in, a.w_in, a.up[2], a.c[2], lane);
+    poff0[it] = pixel_offset(inside, n, iy, ix, a.h_in, a.w_in, a.up[0], a.c[0], lane, tr);
+    poff1[it] = pixel_offset(inside && a.nsrc > 1, n, iy, ix, a.h_in, a.w_in, a.up[1], a.c[1], lane, tr);
+    poff2[it] = pixel_offset(inside && a.nsrc > 2, n, iy, ix, a.h_in, a.w_in, a.up[2], a.c[2], lane, tr);
   }
   const int ng0 = a.c[0] >> 3, ng1 = a.c[1] >> 3;
   const float4* wbase = wp4 + ((size_t)cb * a.groups * TAPS * 2 + half) * 32 + p;
@@ -224,20 +283,35 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
   const float* src2 = a.src[2];
   // K loop, unrolled by two so that the two weight register sets alternate without copies
   float4 wA[TAPS], wB[TAPS];
+  DT_STAMP(1);
   if (g_first < a.groups) {
     DT_PREFETCH_PATCH(g_first);
     DT_LOAD_WEIGHTS(wA, g_first);
   }
   for (int g = g_first; g < a.groups; g += 2 * g_step) {
     DT_K_STEP(wA, wB, g);
+#ifdef DT_CONV_TIMING
+    if (g == g_first) {
+      asm volatile("s_nop 0" ::"v"(acc[0]));  // the first step's MFMAs have produced their result
+      DT_STAMP(2);
+    }
+#endif
     if (g + g_step < a.groups) DT_K_STEP(wB, wA, g + g_step);
   }
+#ifdef DT_CONV_TIMING
+  asm volatile("s_nop 0" ::"v"(acc[0]));
+  DT_STAMP(3);
+  if (a.timing && lane == 0 && wave < 8) {  // per wave: end of its K loop, and where it runs (HW_ID: SIMD, CU, ...)
+    a.timing[(size_t)vblock * 24 + 8 + wave] = __builtin_amdgcn_s_memrealtime();
+    a.timing[(size_t)vblock * 24 + 16 + wave] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, all 32 bits
+  }
+#endif
 #undef DT_K_STEP
 #undef DT_LOAD_WEIGHTS
 #undef DT_PREFETCH_PATCH
 
   const bool in_image = have_block && oy < a.h_out && ox < a.w_out;
-  const size_t pix_off = (((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out;
+  const size_t pix_off = (tr ? ((size_t)n * a.w_out + ox) * a.h_out + oy : ((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out;
 
   auto finish = [&](float4 o, int co) {
     const size_t off = pix_off + co;
@@ -271,12 +345,14 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
     }
   } else {
     // ---- cross-wave K reduction through LDS, epilogue by the first four waves -------------------
-    __syncthreads();  // every wave is done reading its patch
+    // a wave parks its accumulators in ITS OWN patch region (its last patch reads precede these writes in program order,
+    // and a wave's LDS operations complete in order), so the early finishers do this while the others still compute
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) tile[r * 64 + lane] = acc[r];
     __syncthreads();
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (wave < 4) {
-      float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = wave * 4 + j;
@@ -285,8 +361,40 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
         for (int u = 0; u < NW; ++u) sum += lds[u * TILE_FLOATS + r * 64 + lane];
         v[j] = sum;
       }
-      if (in_image) finish(make_float4(v[0], v[1], v[2], v[3]), cb * 32 + wave * 8 + half * 4);
+      DT_STAMP(4);
+      if (kparts == 1 && in_image) finish(make_float4(v[0], v[1], v[2], v[3]), cb * 32 + wave * 8 + half * 4);
     }
+    if (kparts > 1 && have_block) {  // (workgroup-uniform)
+      // ---- cross-workgroup K reduction: publish this part, count arrivals, the last one sums in part order ----
+      float4* slot = reinterpret_cast<float4*>(a.part_buf) + ((size_t)blk * kparts * 4 + wave) * 64 + lane;
+      if (wave < 4) store_f4_coherent(slot + (size_t)part * 256, make_float4(v[0], v[1], v[2], v[3]));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // every partial store of this workgroup has been acknowledged; the reduction reads of lds are done
+      unsigned* flag = reinterpret_cast<unsigned*>(lds);
+      if (threadIdx.x == 0)
+        *flag = __hip_atomic_fetch_add(a.part_cnt + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const unsigned arrived = *reinterpret_cast<volatile unsigned*>(flag);
+      if (arrived == (unsigned)(kparts - 1)) {
+        if (wave < 4) {
+          float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int q = 0; q < kparts; ++q) {
+            // own part from registers (bit-identical to what was stored): the sum does not depend on who arrives last
+            const float4 pv = (q == part) ? make_float4(v[0], v[1], v[2], v[3]) : load_f4_coherent(slot + (size_t)q * 256);
+            sum.x = (q == 0) ? pv.x : sum.x + pv.x;
+            sum.y = (q == 0) ? pv.y : sum.y + pv.y;
+            sum.z = (q == 0) ? pv.z : sum.z + pv.z;
+            sum.w = (q == 0) ? pv.w : sum.w + pv.w;
+          }
+          if (in_image) finish(sum, cb * 32 + wave * 8 + half * 4);
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(a.part_cnt + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#ifdef DT_CONV_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the output stores have been acknowledged
+    DT_STAMP(5);
+#endif
   }
 }
 
@@ -911,7 +1019,8 @@ __global__ void upsample2x_bilinear_kernel(const float* __restrict__ in, float* 
 }
 
 static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* bias,
-                     const float* res, float* out, ConvArgs& a, const char* who, bool any_channels = false) {
+                     const float* res, float* out, ConvArgs& a, const char* who, bool any_channels = false,
+                     bool allow_tr = false) {
   DT_REQUIRE(d != nullptr, "%s: null descriptor", who);
   DT_REQUIRE(d->n > 0 && d->h_out > 0 && d->w_out > 0 && d->h_in > 0 && d->w_in > 0, "%s: bad extents", who);
   DT_REQUIRE(d->nsrc >= 1 && d->nsrc <= 3, "%s: nsrc=%d not in 1..3", who, d->nsrc);
@@ -947,12 +1056,25 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
   a.bias = bias;
   a.res = res;
   a.out = out;
+  DT_REQUIRE(d->transposed == 0 || d->transposed == 1, "%s: transposed=%d (0 or 1)", who, d->transposed);
+  DT_REQUIRE(!d->transposed || allow_tr, "%s: transposed tiling is only implemented by the K-split kernels of dt_conv2d_f32 / dt_conv2d_pair_f32", who);
+#ifdef DT_CONV_TIMING
+  {
+    const char* e = getenv("DT_CONV_TIMING_PTR");
+    a.timing = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
+  }
+#endif
+  a.tr = d->transposed;
+  a.kparts = 1;
+  a.kplain = 0;
+  a.part_buf = nullptr;
+  a.part_cnt = nullptr;
   a.n = d->n;
-  a.h_out = d->h_out;
-  a.w_out = d->w_out;
+  a.h_out = a.tr ? d->w_out : d->h_out;  // (the kernels work in the transposed frame)
+  a.w_out = a.tr ? d->h_out : d->w_out;
   a.c_out = d->c_out;
-  a.h_in = d->h_in;
-  a.w_in = d->w_in;
+  a.h_in = a.tr ? d->w_in : d->h_in;
+  a.w_in = a.tr ? d->h_in : d->w_in;
   a.act = d->act;
   a.pad_replicate = d->pad_mode;
   static const int xcd_remap = [] { const char* e = getenv("DT_CONV_XCD_REMAP"); return e ? atoi(e) : 1; }();
@@ -960,9 +1082,171 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
   static const int cb_major_mode = [] { const char* e = getenv("DT_CONV_CB_MAJOR"); return e ? atoi(e) : 1; }();
   // weights (c_out x K x taps) outweigh the input (pixels x K) when pixels < c_out x taps
   a.cb_major = cb_major_mode && ((long)d->n * d->h_out * d->w_out < (long)d->c_out * d->ksize * d->ksize);
-  a.tiles_x = (d->w_out + kPW - 1) / kPW;
-  a.tiles_y = (d->h_out + kPH - 1) / kPH;
+  a.tiles_x = (a.w_out + kPW - 1) / kPW;
+  a.tiles_y = (a.h_out + kPH - 1) / kPH;
   a.co_blocks = d->c_out / 32;
+  return 0;
+}
+
+// ---- cross-workgroup K split: policy and workspace ---------------------------------------------------------------------
+static int device_cus() {
+  static int cus = 0;
+  if (cus <= 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    cus = n;
+  }
+  return cus;
+}
+
+// Number of workgroups P that share one output block of a K-split kernel.  Measured on the K-split kernels
+// (scripts/conv_quantisation.py, profiles/r2p_conv_quantisation.txt): a launch lasts about
+//     4 us + max over CUs of the sum over the CU's workgroups of (4.1 us + K steps per wave x waves per SIMD x step time),
+// i.e. a workgroup's own latency chain (kernel arguments, first loads, reduction, epilogue: ~4 us) is NOT hidden by other
+// workgroups of the same CU -- they all start together and move through their phases in lockstep -- and a second "round" of
+// workgroups costs a full extra term (320 blocks of the 30x40 level: 27 us, 256 blocks: 16 us).  Splitting K over P
+// workgroups therefore pays exactly when the P-fold workgroup count still fits one round (15x20 level: 120 blocks x 2 ->
+// 14.8 instead of 20.6 us), and costs otherwise.  The model below ranks the candidates; workgroups are assumed to be dealt
+// to the CUs round-robin in launch order.
+struct KSeg {
+  long blocks;  // output blocks of this convolution
+  int groups, split, ksize;
+  bool can_split;  // cross-workgroup split implemented for this body
+};
+static double launch_cost_us(const KSeg* seg, const int* P, int nseg, int cus) {
+  // per-CU load of a round-robin deal: segment workgroups [o, o + n) put ceil/floor(n / cus) on every CU
+  double best = 0.0;
+  long o = 0;
+  // loads of the (at most cus) distinct CUs; n is small (a few hundred), so the direct form is fine
+  static thread_local std::vector<double> load;
+  load.assign((size_t)cus, 0.0);
+  for (int i = 0; i < nseg; ++i) {
+    const long n = seg[i].blocks * P[i];
+    const long steps = (seg[i].groups + (long)seg[i].split * P[i] - 1) / ((long)seg[i].split * P[i]);
+    const double step_us = seg[i].ksize * seg[i].ksize * 4 * 64 / 2400.0;  // 4 MFMAs x 64 cycles per tap and group
+    const double wg = 4.1 + (P[i] > 1 ? 0.7 : 0.0) + (double)steps * step_us * (seg[i].split / 4.0);
+    const long full = n / cus, rem = n % cus;
+    for (int c = 0; c < cus; ++c) {
+      const long pos = (c - o % cus + cus) % cus;  // CU c is the pos-th to receive a workgroup of this segment
+      load[(size_t)c] += (double)(full + (pos < rem ? 1 : 0)) * wg;
+    }
+    o += n;
+  }
+  for (int c = 0; c < cus; ++c) best = load[(size_t)c] > best ? load[(size_t)c] : best;
+  return best;
+}
+static void plan_kparts(const KSeg* seg, int nseg, int* P) {
+  static const int forced = [] { const char* e = getenv("DT_CONV_KPARTS"); return e ? atoi(e) : 0; }();
+  for (int i = 0; i < nseg; ++i) P[i] = 1;
+  if (forced == 1 || forced == 2 || forced == 4) {
+    for (int i = 0; i < nseg; ++i)
+      if (seg[i].can_split && seg[i].groups >= seg[i].split * forced) P[i] = forced;
+    return;
+  }
+  // memo: the plan depends only on the launch shape
+  typedef std::array<long, 8> Key;
+  static std::mutex mtx;
+  static std::map<Key, std::array<int, 2>> memo;
+  Key key{};
+  for (int i = 0; i < nseg && i < 2; ++i) {
+    key[(size_t)i * 4 + 0] = seg[i].blocks;
+    key[(size_t)i * 4 + 1] = seg[i].groups;
+    key[(size_t)i * 4 + 2] = seg[i].split * 2 + (seg[i].can_split ? 1 : 0);
+    key[(size_t)i * 4 + 3] = seg[i].ksize;
+  }
+  std::lock_guard<std::mutex> lock(mtx);
+  auto it = memo.find(key);
+  if (it == memo.end()) {
+    const int cus = device_cus();
+    std::array<int, 2> best = {1, 1};
+    int cand[2] = {1, 1};
+    double best_cost = launch_cost_us(seg, cand, nseg, cus);
+    for (int pa = 1; pa <= 4; pa *= 2)
+      for (int pb = 1; pb <= (nseg > 1 ? 4 : 1); pb *= 2) {
+        cand[0] = pa;
+        cand[1] = pb;
+        bool ok = true;
+        for (int i = 0; i < nseg; ++i)
+          ok = ok && (cand[i] == 1 || (seg[i].can_split && seg[i].groups >= seg[i].split * cand[i]));
+        if (!ok) continue;
+        const double c = launch_cost_us(seg, cand, nseg, cus);
+        if (c < best_cost - 0.75) {  // keep the plain launch unless the split clearly wins
+          best_cost = c;
+          best = {pa, pb};
+        }
+      }
+    it = memo.emplace(key, best).first;
+  }
+  for (int i = 0; i < nseg && i < 2; ++i) P[i] = it->second[(size_t)i];
+}
+
+// Scratch of the cross-workgroup reduction: one per (device, stream), grown on demand, never shrunk.  Launches on one stream
+// are ordered, so consecutive layers reuse it; the counters are zero whenever no launch is in flight (the last workgroup to
+// arrive at a block resets its counter).  Two host threads driving the SAME stream concurrently are not supported.
+struct ConvScratch {
+  float* parts = nullptr;
+  unsigned* cnt = nullptr;
+  size_t part_floats = 0, counters = 0;
+};
+static std::mutex g_scratch_mutex;
+static std::map<std::pair<int, hipStream_t>, ConvScratch> g_scratch;
+
+static int conv_scratch(hipStream_t st, size_t part_floats, size_t counters, float** parts, unsigned** cnt) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail("conv scratch: no current device");
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  ConvScratch& ws = g_scratch[std::make_pair(dev, st)];
+  if (ws.part_floats < part_floats || ws.counters < counters) {
+    // growing: earlier launches on this stream may still use the old buffers
+    if (ws.parts || ws.cnt) {
+      if (hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail("conv scratch: cannot synchronise the stream before growing (stream capture in progress?)");
+      }
+      (void)hipFree(ws.parts);
+      (void)hipFree(ws.cnt);
+      ws = ConvScratch();
+    }
+    const size_t pf = part_floats > (size_t)(4u << 20) ? part_floats : (size_t)(4u << 20);  // >= 16 MB
+    const size_t nc = counters > (size_t)16384 ? counters : (size_t)16384;
+    if (hipMalloc(&ws.parts, pf * sizeof(float)) != hipSuccess || hipMalloc(&ws.cnt, nc * sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(ws.cnt, 0, nc * sizeof(unsigned), st) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(ws.parts);
+      (void)hipFree(ws.cnt);
+      ws = ConvScratch();
+      return fail("conv scratch: cannot allocate %zu + %zu bytes", pf * sizeof(float), nc * sizeof(unsigned));
+    }
+    ws.part_floats = pf;
+    ws.counters = nc;
+  }
+  *parts = ws.parts;
+  *cnt = ws.cnt;
+  return 0;
+}
+
+// attach scratch at the given offsets (a pair launch gives its two convolutions disjoint slices)
+static int attach_scratch(hipStream_t st, ConvArgs* a, long blocks_a, ConvArgs* b, long blocks_b) {
+  const long sa = (a && a->kparts > 1) ? blocks_a - a->kplain : 0, sb = (b && b->kparts > 1) ? blocks_b - b->kplain : 0;
+  const size_t fa = (size_t)sa * (a ? a->kparts : 0) * 1024, fb = (size_t)sb * (b ? b->kparts : 0) * 1024;
+  if (fa + fb == 0) return 0;
+  float* parts = nullptr;
+  unsigned* cnt = nullptr;
+  if (int rc = conv_scratch(st, fa + fb, (size_t)(sa + sb), &parts, &cnt)) return rc;
+  if (fa) {
+    a->part_buf = parts;
+    a->part_cnt = cnt;
+  }
+  if (fb) {
+    b->part_buf = parts + fa;
+    b->part_cnt = cnt + sa;
+  }
   return 0;
 }
 
@@ -995,7 +1279,7 @@ int dt_conv_pack_f32(const float* W, float* packed, int c_out, int c_in, int ksi
 int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* packed_w,
                   const float* bias, const float* residual, float* out, dt_stream_t s) {
   ConvArgs a;
-  if (int rc = fill_args(d, in0, in1, in2, bias, residual, out, a, "dt_conv2d_f32")) return rc;
+  if (int rc = fill_args(d, in0, in1, in2, bias, residual, out, a, "dt_conv2d_f32", false, /*allow_tr=*/true)) return rc;
   DT_REQUIRE(packed_w != nullptr, "dt_conv2d_f32: null weights");
   DT_REQUIRE(d->c_out > 0 && d->c_out % 32 == 0, "dt_conv2d_f32: c_out=%d must be a multiple of 32", d->c_out);
   a.wp = packed_w;
@@ -1008,15 +1292,37 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
   int split = 4;
   if (blocks >= 4096 || k_steps <= 16) split = 1;  // (at 1200 blocks the 4-way K split measured faster)
   else if (blocks * 4 < 2048 && a.groups >= 16) split = 8;
+  static const int force_split = [] { const char* e = getenv("DT_CONV_SPLIT"); return e ? atoi(e) : 0; }();
+  if (split != 1 && (force_split == 4 || force_split == 8)) split = force_split;
+  long grid = blocks;
+  if (d->ksize == 3 && split != 1) {
+    const KSeg seg = {blocks, a.groups, split, 3, true};
+    plan_kparts(&seg, 1, &a.kparts);
+    // a few blocks more than CUs (the 30x40 level: 320 on 256): one whole block per CU first, and only the leftovers are
+    // split, into about one small workgroup per CU -- a second round of 1/P-sized instead of full-sized workgroups
+    static const int tail_mode = [] { const char* e = getenv("DT_CONV_TAIL_SPLIT"); return e ? atoi(e) : 1; }();
+    const int cus = device_cus();
+    if (tail_mode && a.kparts == 1 && blocks > cus && blocks < 2L * cus && cus % 8 == 0) {
+      const long rest = blocks - cus;
+      const int P = (rest * 4 <= cus + cus / 4) ? 4 : 2;  // rest x P ~ one workgroup per CU
+      if (a.groups >= split * P) {
+        a.kparts = P;
+        a.kplain = cus;
+      }
+    }
+    grid = a.kplain + (blocks - a.kplain) * a.kparts;
+    if (int rc = attach_scratch(st, &a, blocks, nullptr, 0)) return rc;
+  }
 #define DT_LAUNCH_CONV(KS_, ST_)                                                                                   \
   do {                                                                                                             \
+    DT_REQUIRE(!a.tr || split != 1, "dt_conv2d_f32: transposed tiling needs a K-split kernel (see dt_conv_transposed_tiling)"); \
     if (split == 1)                                                                                                \
       hipLaunchKernelGGL((conv_mfma_wshare_kernel<KS_, ST_>),                                                      \
                          dim3((unsigned)((((long)a.n * a.tiles_y * a.tiles_x + 3) / 4) * a.co_blocks)), dim3(256), 0, st, a); \
     else if (split == 4)                                                                                           \
-      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a);             \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);               \
     else                                                                                                           \
-      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 8>), dim3((unsigned)blocks), dim3(512), 0, st, a);             \
+      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);               \
   } while (0)
   if (d->ksize == 3 && d->stride == 1)
     DT_LAUNCH_CONV(3, 1);
@@ -1031,11 +1337,30 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
       launch_split16<1, 1>(a, blocks, st);
     else if (waves < 1024 && a.groups >= 16)
       hipLaunchKernelGGL((conv_mfma_kernel<1, 1, 8>), dim3((unsigned)blocks), dim3(512), 0, st, a);
-    else
+    else {
+      DT_REQUIRE(!a.tr, "dt_conv2d_f32: transposed tiling needs a K-split kernel (see dt_conv_transposed_tiling)");
       hipLaunchKernelGGL(conv1x1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    }
   }
 #undef DT_LAUNCH_CONV
   return check_launch("dt_conv2d_f32");
+}
+
+int dt_conv_transposed_tiling(const dt_conv_desc* d) {
+  if (!d || d->nsrc < 1 || d->nsrc > 3 || d->c_out <= 0 || d->c_out % 32 != 0 || (d->ksize != 1 && d->ksize != 3)) return 0;
+  int groups = 0;
+  for (int s = 0; s < d->nsrc; ++s) {
+    if (d->c[s] <= 0 || d->c[s] % 8 != 0) return 0;
+    groups += d->c[s] >> 3;
+  }
+  auto px_tiles = [&](int h, int w) { return (long)((h + kPH - 1) / kPH) * ((w + kPW - 1) / kPW); };
+  const long t_n = px_tiles(d->h_out, d->w_out), t_t = px_tiles(d->w_out, d->h_out);
+  if (t_t >= t_n) return 0;
+  // the transposed launch must land on a K-split kernel (same rules as dt_conv2d_f32 with the transposed block count)
+  const long blocks = (long)d->n * t_t * (d->c_out / 32);
+  if (d->ksize == 3) return (blocks < 4096 && (long)groups * 9 > 16) ? 1 : 0;
+  const long waves = (((long)d->n * d->h_out * d->w_out + 31) / 32) * (d->c_out / 32);
+  return (waves < 1024 && groups >= 16) ? 1 : 0;
 }
 
 int64_t dt_conv_wino_pack_floats(int c_out, int c_in) { return (int64_t)c_out * c_in * 16; }
@@ -1099,8 +1424,8 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
                        const float* packed_wa, int a_wino, const float* bias_a, float* out_a, const float* packed_wb,
                        const float* bias_b, float* out_b, dt_stream_t s) {
   ConvArgs a, b;
-  if (int rc = fill_args(da, in0, in1, in2, bias_a, nullptr, out_a, a, "dt_conv2d_pair_f32(A)")) return rc;
-  if (int rc = fill_args(db, in0, in1, in2, bias_b, nullptr, out_b, b, "dt_conv2d_pair_f32(B)")) return rc;
+  if (int rc = fill_args(da, in0, in1, in2, bias_a, nullptr, out_a, a, "dt_conv2d_pair_f32(A)", false, /*allow_tr=*/!a_wino)) return rc;
+  if (int rc = fill_args(db, in0, in1, in2, bias_b, nullptr, out_b, b, "dt_conv2d_pair_f32(B)", false, /*allow_tr=*/true)) return rc;
   DT_REQUIRE(packed_wa && packed_wb, "dt_conv2d_pair_f32: null weights");
   DT_REQUIRE(da->c_out % 32 == 0 && db->c_out % 32 == 0, "dt_conv2d_pair_f32: c_out must be a multiple of 32");
   DT_REQUIRE(da->ksize == 3 && da->stride == db->stride && da->h_out == db->h_out && da->w_out == db->w_out && da->n == db->n,
@@ -1123,6 +1448,17 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
                        (unsigned)(NA));                                                                                   \
     return check_launch("dt_conv2d_pair_f32");                                                                            \
   } while (0)
+  // direct 3x3 K-split bodies: same cross-workgroup split as the single launch would choose (bit-equal results)
+#define DT_PAIR_KP(BA, BB, SPLIT_A, SPLIT_B)                                                                              \
+  do {                                                                                                                    \
+    const KSeg seg[2] = {{blocks_a, a.groups, SPLIT_A, 3, true}, {blocks_b, b.groups, SPLIT_B, db->ksize, true}};          \
+    int P[2];                                                                                                             \
+    plan_kparts(seg, 2, P);                                                                                               \
+    a.kparts = P[0];                                                                                                      \
+    b.kparts = P[1];                                                                                                      \
+    if (int rc = attach_scratch(st, &a, blocks_a, &b, blocks_b)) return rc;                                               \
+    DT_PAIR(BA, BB, blocks_a * P[0], blocks_b * P[1]);                                                                    \
+  } while (0)
   if (a_wino) {
     const long wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
     const long blocks_a = (long)a.n * wt_y * wt_x * a.co_blocks;
@@ -1136,10 +1472,11 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
     const long blocks_a = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
     const ConvPick pa = pick_direct(a, da);
     if (da->stride == 1 && pa == PICK_SPLIT8 && (pb == PICK_1X1_SPLIT8 || pb == PICK_1X1_SPLIT16))
-      DT_PAIR(M318, M118, blocks_a, blocks_b);
-    if (da->stride == 2 && pa == PICK_SPLIT8 && pb == PICK_SPLIT8) DT_PAIR(M328, M328, blocks_a, blocks_b);
-    if (da->stride == 2 && pa == PICK_SPLIT4 && pb == PICK_SPLIT4) DT_PAIR(M324, M324, blocks_a, blocks_b);
+      DT_PAIR_KP(M318, M118, 8, 8);
+    if (da->stride == 2 && pa == PICK_SPLIT8 && pb == PICK_SPLIT8) DT_PAIR_KP(M328, M328, 8, 8);
+    if (da->stride == 2 && pa == PICK_SPLIT4 && pb == PICK_SPLIT4) DT_PAIR_KP(M324, M324, 4, 4);
   }
+#undef DT_PAIR_KP
 #undef DT_PAIR
   // no common workgroup shape: two launches
   int rc = a_wino ? dt_conv2d_wino_f32(da, in0, in1, in2, packed_wa, bias_a, nullptr, out_a, s)

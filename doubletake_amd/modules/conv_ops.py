@@ -7,6 +7,7 @@ torch op, so every module stays a drop-in at its own boundary.
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 
 import torch
 import torch.nn as nn
@@ -47,11 +48,13 @@ def as_nhwc(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def packed_weight(conv: nn.Conv2d, device):
-    """Device buffer with conv.weight re-packed for the MFMA kernel; cached per weight version."""
+def packed_weight(conv: nn.Conv2d, device, transposed=False):
+    """Device buffer with conv.weight re-packed for the MFMA kernel; cached per weight version.
+    transposed: pack W.transpose(2, 3) (for launches with dt_conv_desc.transposed = 1)."""
     w = conv.weight
     key = (w.data_ptr(), w._version, str(device))
-    hit = getattr(conv, "_dt_pack", None)
+    slot = "_dt_pack_t" if transposed else "_dt_pack"
+    hit = getattr(conv, slot, None)
     if hit is not None and hit[0] == key:
         return hit[1]
     co, ci, k, k2 = w.shape
@@ -59,12 +62,21 @@ def packed_weight(conv: nn.Conv2d, device):
             or conv.padding_mode not in ("zeros", "replicate")):
         raise NotImplementedError(f"unsupported conv configuration {conv}")
     L = _abi.lib()
-    wd = w.detach().to(device=device, dtype=torch.float32).contiguous()
+    wd = w.detach().to(device=device, dtype=torch.float32)
+    wd = (wd.transpose(2, 3) if transposed else wd).contiguous()
     packed = torch.empty(int(L.dt_conv_pack_floats(co, ci, k)), device=device, dtype=torch.float32)
     _abi.check(L.dt_conv_pack_f32(_abi.ptr(wd), _abi.ptr(packed), co, ci, k, _abi.current_stream(device)),
                "dt_conv_pack_f32")
-    conv._dt_pack = (key, packed)
+    setattr(conv, slot, (key, packed))
     return packed
+
+
+#: tile small maps in the transposed frame when that needs fewer workgroups (DT_CONV_TRANSPOSE=0 disables; A/B switch)
+TRANSPOSED_TILING = _os.environ.get("DT_CONV_TRANSPOSE", "1") != "0"
+
+
+def _want_transposed(L, d) -> bool:
+    return bool(TRANSPOSED_TILING and L.dt_conv_transposed_tiling(C.byref(d)))
 
 
 def packed_weight_wino(conv: nn.Conv2d, device):
@@ -88,8 +100,6 @@ def packed_weight_wino(conv: nn.Conv2d, device):
 
 #: use the Winograd kernel for 3x3 stride-1 layers with at least this many 8x16-pixel x 32-channel workgroups
 #: (set by measurement); DT_CONV_WINO_MIN_BLOCKS overrides, 0 disables
-import os as _os  # noqa: E402
-
 WINO_MIN_BLOCKS = int(_os.environ.get("DT_CONV_WINO_MIN_BLOCKS", "128"))
 
 
@@ -164,7 +174,8 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
         _abi.check(L.dt_conv2d_wino_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wp), _abi.ptr(bias),
                                         _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_wino_f32")
     elif impl == "mfma":
-        wp = packed_weight(conv, dev)
+        d.transposed = 1 if _want_transposed(L, d) else 0
+        wp = packed_weight(conv, dev, transposed=bool(d.transposed))
         _abi.check(L.dt_conv2d_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wp), _abi.ptr(bias),
                                    _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_f32")
     else:
@@ -216,8 +227,11 @@ def conv2d_pair(srcs, conv_a: nn.Conv2d, act_a, conv_b: nn.Conv2d, act_b):
     a_wino = False
     if sa == 1 and WINO_MIN_BLOCKS > 0:
         a_wino = da.n * ((da.h_out + 7) // 8) * ((da.w_out + 15) // 16) * (co_a // 32) >= WINO_MIN_BLOCKS
-    wa = packed_weight_wino(conv_a, dev) if a_wino else packed_weight(conv_a, dev)
-    wb = packed_weight(conv_b, dev)
+    if not a_wino:
+        da.transposed = 1 if _want_transposed(L, da) else 0
+    db.transposed = 1 if _want_transposed(L, db) else 0
+    wa = packed_weight_wino(conv_a, dev) if a_wino else packed_weight(conv_a, dev, transposed=bool(da.transposed))
+    wb = packed_weight(conv_b, dev, transposed=bool(db.transposed))
     out_a = empty_nhwc(da.n, co_a, da.h_out, da.w_out, dev)
     out_b = empty_nhwc(db.n, co_b, db.h_out, db.w_out, dev)
     _abi.check(L.dt_conv2d_pair_f32(C.byref(da), C.byref(db), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wa), int(a_wino),

@@ -160,6 +160,10 @@ typedef struct dt_conv_desc {
   int act;                  /* DT_ACT_* */
   int h_in, w_in;           /* extent of the (virtual, post-upsample) input */
   int pad_mode;             /* 0: zero padding; 1: replicate (nn.Conv2d padding_mode="replicate") */
+  int transposed;           /* 1: tile the image with tall 8x4 instead of 4x8 output patches (fewer partly empty tiles
+                             * on maps such as 15x20); packed_w must then come from the weight with its two spatial
+                             * axes swapped (W.transpose(2,3)).  Extents above stay the real ones, results are the
+                             * same.  Only where dt_conv_transposed_tiling() returns 1; 0 everywhere else. */
 } dt_conv_desc;
 
 int64_t dt_conv_pack_floats(int c_out, int c_in, int ksize);
@@ -170,6 +174,10 @@ int dt_conv_pack_f32(const float* W_oihw, float* packed, int c_out, int c_in, in
 int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2,
                   const float* packed_w, const float* bias, const float* residual,
                   float* out, dt_stream_t s);
+/* 1 when dt_conv2d_f32 / dt_conv2d_pair_f32 (direct kernels) would run this convolution with fewer workgroups in the
+ * transposed tiling (d->transposed is ignored on input); the caller then sets d->transposed = 1 and passes weights packed
+ * from W.transpose(2,3). */
+int dt_conv_transposed_tiling(const dt_conv_desc* d);
 /* Winograd F(2x2,3x3) variant for 3x3 stride-1 convolutions (2.25x fewer multiplies; same fp32
  * arithmetic type, different summation order: results agree with dt_conv2d_f32 to ~1e-6 relative).
  * packed_w: dt_conv_wino_pack_floats floats made by dt_conv_wino_pack_f32 from the OIHW weight. */
