@@ -118,6 +118,15 @@ struct ConvMfmaCfg {
   static constexpr int THREADS = NW * 64;
 };
 
+// Workgroups per CU requested from the compiler (register budget = 512 / waves per SIMD).  1 = whatever the kernels need
+// (128-160 VGPRs: one 512-thread workgroup per CU).  Experiment knob: -DDT_CONV_OCC=2 caps the 512-thread kernels at 128
+// VGPRs so that two workgroups (e.g. of two HIP streams) share a CU -- measured 4 % SLOWER on bench.py in both the one- and
+// the two-stream mode (623 vs 648 frames/s): the spills land in the K loop and co-resident workgroups move in lockstep.
+#ifndef DT_CONV_OCC
+#define DT_CONV_OCC 1
+#endif
+constexpr int conv_waves_per_eu(int threads) { return threads / 256 * DT_CONV_OCC; }
+
 // -DDT_CONV_TIMING: wave 0 of every workgroup of the K-split kernels records s_memrealtime (100 MHz) at its phase
 // boundaries into the buffer whose address the host reads from the environment (scripts/conv_phase_timing.py).
 #ifdef DT_CONV_TIMING
@@ -399,7 +408,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
 }
 
 template <int KS, int ST, int SPLIT>
-__global__ __launch_bounds__((ConvMfmaCfg<KS, ST, SPLIT>::THREADS)) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__((ConvMfmaCfg<KS, ST, SPLIT>::THREADS), (conv_waves_per_eu(ConvMfmaCfg<KS, ST, SPLIT>::THREADS))) void conv_mfma_kernel(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[ConvMfmaCfg<KS, ST, SPLIT>::LDS_FLOATS];
   conv_mfma_body<KS, ST, SPLIT>(a, lds, blockIdx.x, gridDim.x);
 }
@@ -830,7 +839,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
 }
 
 template <int KSPLIT>
-__global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256 * KSPLIT, conv_waves_per_eu(256 * KSPLIT)) void conv_wino_kernel(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_all[8192 * KSPLIT];
   conv_wino_body<KSPLIT>(a, lds_all, blockIdx.x, gridDim.x);
 }
@@ -842,7 +851,7 @@ __global__ __launch_bounds__(256 * KSPLIT) void conv_wino_kernel(const ConvArgs 
 // blocks [0, nblocks_a) run convolution A, the rest convolution B, each with its own ConvArgs and virtual block index.
 // Both bodies must use the same workgroup size.
 template <class BodyA, class BodyB>
-__global__ __launch_bounds__(BodyA::THREADS) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, unsigned nblocks_a) {
+__global__ __launch_bounds__(BodyA::THREADS, conv_waves_per_eu(BodyA::THREADS)) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, unsigned nblocks_a) {
   static_assert(BodyA::THREADS == BodyB::THREADS, "paired convolutions need equal workgroup sizes");
   constexpr int LDSF = BodyA::LDS_FLOATS > BodyB::LDS_FLOATS ? BodyA::LDS_FLOATS : BodyB::LDS_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDSF > 0 ? LDSF : 4];
