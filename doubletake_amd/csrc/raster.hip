@@ -3,12 +3,15 @@
 // Replaces the PyTorch3D MeshRasterizer call of the reference's hint renderer
 // (utils/rendering_utils.py:9-53: image_size=(h,w), blur_radius=0, faces_per_pixel=1, perspective
 // cameras built by cameras_from_opencv_projection; only fragments.zbuf is used, background -1).
-// Semantics restated: a pixel is covered by a triangle when its centre (x+0.5, y+0.5) lies inside
+// Semantics restated: a pixel is covered by a triangle when its centre (x+0.5, y+0.5) lies STRICTLY inside
 // the projected triangle (no back-face culling); zbuf is the perspective-correct depth
 // 1 / sum(b_i / z_i) of the nearest such triangle.  Faces with a vertex closer than z = 1e-2 are
-// dropped (PyTorch3D clips them at that plane; they are centimetre-sized triangles at the camera).
-// PyTorch3D 0.7.4 is not installed here, so parity with it is UNPINNED; the oracle is an independent
-// numpy restatement of the semantics above (oracle/raster_ref.py).
+// dropped (stated deviation: PyTorch3D has no near clip for PerspectiveCameras and rasterises the
+// wrapped-around projection of faces that cross the camera plane).
+// PyTorch3D 0.7.4 is not installed here; its rules for this call (camera conversion, pixel grid, strict
+// coverage, perspective-correct z, nearest face) are pinned by the hand-derived known-answer cases of
+// tests/golden/make_raster_handcases.py, which this kernel and the independent numpy oracle
+// (oracle/raster_ref.py) both have to reproduce.
 //
 // One thread per triangle, depth test with atomicMin on the IEEE bits (z > 0 => order preserving).
 // Hint meshes are 0.04 m marching-cubes triangles seen from 0.5-3 m: a few pixels each, so the
@@ -53,9 +56,11 @@ __device__ __forceinline__ void raster_triangle(const float (&X)[3], const float
       // barycentrics from edge functions, normalised by the signed area (either winding)
       const float b0 = ((sx[1] - px) * (sy[2] - py) - (sx[2] - px) * (sy[1] - py)) * inv_area;
       const float b1 = ((sx[2] - px) * (sy[0] - py) - (sx[0] - px) * (sy[2] - py)) * inv_area;
-      const float b2 = 1.0f - b0 - b1;
-      if (b0 < 0.f || b1 < 0.f || b2 < 0.f) continue;
-      const float z = 1.0f / (b0 * iz0 + b1 * iz1 + b2 * iz2);
+      const float b2 = ((sx[0] - px) * (sy[1] - py) - (sx[1] - px) * (sy[0] - py)) * inv_area;
+      // PyTorch3D 0.7.4 CheckPixelInsideFace (rasterize_meshes.cu): inside = all three barycentrics STRICTLY positive;
+      // a sample exactly on an edge is covered by neither neighbour (tests/golden/make_raster_handcases.py, rule R3)
+      if (!(b0 > 0.f && b1 > 0.f && b2 > 0.f)) continue;
+      const float z = (b0 + b1 + b2) / (b0 * iz0 + b1 * iz1 + b2 * iz2);  // sum b'_i z_i of the corrected barycentrics
       if (z > 0.f) atomicMin(zb + (size_t)y * w + x, __float_as_uint(z));
     }
   }

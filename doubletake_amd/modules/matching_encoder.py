@@ -15,8 +15,9 @@ and parameter shapes (state dicts of the reference load unchanged):
     net.4  layer1  Sequential(BasicBlock(64,64), BasicBlock(64,64))   conv3x3-bn-relu-conv3x3-bn (+x) relu
     net.5..9       as written in the reference
 
-The anti-aliased stem is restated from memory of antialiased_cnns 0.3 and is UNVERIFIED (DESIGN.md
-section 2); the torchvision variant and everything from net.5 on are plain torch.nn semantics.
+The anti-aliased `maxpool` (the only non-torch layer) follows antialiased_cnns' blurpool.py / resnet.py and is pinned by
+the hand-derived exact cases of tests/golden/make_blurpool_handcases.py; the torchvision variant and everything from
+net.5 on are plain torch.nn semantics.
 
 Eval-mode only (BatchNorm uses running statistics), like every caller in the reference's test scripts.
 """

@@ -16,7 +16,10 @@ semantics.  net.0-net.4 come from `antialiased_cnns.resnet18` / `torchvision.mod
 (networks.py:158-176), neither of which is installed in this image; their structure is restated
 from memory of those packages (torchvision 0.15 resnet.py; antialiased_cnns 0.3 resnet.py + blurpool.py:
 maxpool = Sequential(MaxPool2d(2, stride 1), BlurPool(64, filt_size 4, stride 2, reflect pad (1,2,1,2),
-binomial [1,3,3,1] filter)) and is UNPINNED until one of the packages is available.
+binomial [1,3,3,1] filter)).  The one non-torch layer of that stem, the anti-aliased `maxpool`, is pinned to the package's
+published rules by the hand-derived exact known-answer cases of tests/golden/make_blurpool_handcases.py (this restatement and
+the HIP kernels both reproduce them bit for bit); the composition itself (which children the reference keeps) follows
+networks.py:158-176 and cannot be cross-checked against the package here.
 """
 from __future__ import annotations
 

@@ -1,4 +1,4 @@
-"""GPU: hint-mesh depth rasteriser vs the (unpinned) numpy oracle, and the closed incremental hint loop
+"""GPU: hint-mesh depth rasteriser vs the hand-derived PyTorch3D known-answer cases and the numpy oracle, and the closed incremental hint loop
 fuse -> marching cubes -> render -> sample -> volume -> decoder -> fuse (reference test_incremental.py:187-372)."""
 import numpy as np
 import pytest
@@ -21,6 +21,37 @@ def _fused(nframes=3, H=120, W=160):
     for f in range(nframes):
         fuser.fuse_frames(*(torch.from_numpy(a[f:f + 1]).to(gu.dev()) for a in (depth, K, T)), None)
     return fuser, depth, K, T
+
+
+def _handcases():
+    import json
+    import os
+
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "raster_handcases.json")))
+
+
+@pytest.mark.parametrize("case", _handcases(), ids=lambda c: c["name"])
+def test_raster_reproduces_hand_derived_pytorch3d_cases(case):
+    """dt_raster_depth_f32 (through the reference-shaped MeshDepthRenderer, i.e. with normalised intrinsics) against the
+    known answers derived from PyTorch3D 0.7.4's rules (tests/golden/make_raster_handcases.py): camera conversion, pixel
+    grid of non-square images, STRICT coverage on edges, perspective-correct depth, nearest face, background -1."""
+    import gpu_util as gu
+    from doubletake_amd.tools.tsdf import Meshes
+    from doubletake_amd.utils.rendering_utils import MeshDepthRenderer
+
+    h, w = case["h"], case["w"]
+    want = np.asarray(case["expected"], dtype=np.float64)
+    verts = torch.tensor(case["verts"], dtype=torch.float32, device=gu.dev())
+    faces = torch.tensor(case["faces"], dtype=torch.int64, device=gu.dev())
+    K = torch.tensor(case["K"], dtype=torch.float32, device=gu.dev())[None].clone()
+    K[:, 0] /= w
+    K[:, 1] /= h
+    T = torch.tensor(case["cam_T_world"], dtype=torch.float32, device=gu.dev())[None]
+    got, _ = MeshDepthRenderer(h, w).render(Meshes(verts=[verts], faces=[faces]), T, K)
+    got = got[0, 0].cpu().numpy()
+    np.testing.assert_array_equal(got > 0, want > 0)
+    np.testing.assert_allclose(got[want > 0], want[want > 0], rtol=2e-6)
+    assert np.all(got[want < 0] == -1)
 
 
 def test_raster_vs_oracle_on_fused_mesh():

@@ -224,3 +224,55 @@ def test_feature_cache_is_keyed_by_scan_and_weights():
     c_cur, _ = model.compute_matching_feats(img(1), src(2), scan_ids="scene0707_00", **ids)
     want, _ = model.compute_matching_feats(img(1), src(2))
     assert len(cache) == 3 and (c_cur - want).abs().max() < 1e-4 and (c_cur - a_cur).abs().max() > 1e-3
+
+
+def _blur_handcases():
+    import json
+    import os
+
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "blurpool_handcases.json")))
+
+
+_SCALES = (1.0, 2.0, 4.0, 0.5)  # four channels (the kernels work on channel quads); positive, so max commutes
+
+
+@pytest.mark.parametrize("case", _blur_handcases(), ids=lambda c: c["name"])
+def test_antialiased_maxpool_restatement_reproduces_hand_derived_cases(case):
+    """The torch restatement the oracle uses for `antialiased_cnns` maxpool = Sequential(MaxPool2d(2, 1), BlurPool(64, 4, 2))
+    against answers derived from the package's published rules in exact arithmetic (tests/golden/make_blurpool_handcases.py):
+    EXACT equality -- every expected value is a small multiple of 1/64."""
+    import torch.nn.functional as F
+
+    from doubletake_amd.modules import matching_encoder as me
+
+    x = torch.tensor(case["x"], dtype=torch.float32)[None, None] * torch.tensor(_SCALES).view(1, 4, 1, 1)
+    blur = me.BlurPool(4)
+    a = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    assert torch.equal(blur.filt, (a[:, None] * a[None, :] / 64.0)[None, None].repeat(4, 1, 1, 1))
+    m = F.max_pool2d(x, kernel_size=2, stride=1)
+    assert torch.equal(m[0, 0], torch.tensor(case["maxpool2_s1"], dtype=torch.float32))
+    got = F.conv2d(F.pad(m, (1, 2, 1, 2), mode="reflect"), blur.filt, stride=2, groups=4)
+    for ch, sc in enumerate(_SCALES):
+        assert torch.equal(got[0, ch], torch.tensor(case["maxblur"], dtype=torch.float32) * sc), (case["name"], ch)
+    got_b = F.conv2d(F.pad(x, (1, 2, 1, 2), mode="reflect"), blur.filt, stride=2, groups=4)
+    assert torch.equal(got_b[0, 0], torch.tensor(case["blur"], dtype=torch.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _blur_handcases(), ids=lambda c: c["name"])
+def test_antialiased_maxpool_kernels_reproduce_hand_derived_cases(case):
+    """dt_maxblur_f32 (fused), dt_maxpool_f32 + dt_blurpool4_s2_f32 (separate) against the same hand-derived answers, exactly."""
+    import gpu_util as gu
+    from doubletake_amd.modules import conv_ops as ops
+    from doubletake_amd.modules import matching_encoder as me
+
+    x = torch.tensor(case["x"], dtype=torch.float32)[None, None] * torch.tensor(_SCALES).view(1, 4, 1, 1)
+    xd = ops.as_nhwc(x.to(gu.dev()))
+    blur = me.BlurPool(4).to(gu.dev())
+    want = torch.tensor(case["maxblur"], dtype=torch.float32)
+    fused = me.maxblur(xd, blur).cpu()
+    two = me.blurpool(me.maxpool(xd, 2, 1, 0), blur).cpu()
+    alone = me.blurpool(xd, blur).cpu()
+    for ch, sc in enumerate(_SCALES):
+        assert torch.equal(fused[0, ch], want * sc) and torch.equal(two[0, ch], want * sc), (case["name"], ch)
+        assert torch.equal(alone[0, ch], torch.tensor(case["blur"], dtype=torch.float32) * sc)

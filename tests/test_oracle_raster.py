@@ -1,5 +1,10 @@
-"""Sanity of the (unpinned) depth-render oracle on analytic scenes.  CPU only."""
+"""The depth-render oracle against the hand-derived PyTorch3D 0.7.4 known-answer cases (tests/golden/raster_handcases.json,
+derivation and citations in tests/golden/make_raster_handcases.py) and on analytic scenes.  CPU only."""
+import json
+import os
+
 import numpy as np
+import pytest
 
 from oracle import raster_ref
 
@@ -11,10 +16,16 @@ def test_fronto_parallel_quad_and_occlusion():
     verts = np.array([[-5, -5, 2], [5, -5, 2], [5, 5, 2], [-5, 5, 2], [-0.2, -0.2, 1], [0.2, -0.2, 1], [0.2, 0.2, 1], [-0.2, 0.2, 1.0]])
     faces = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [6, 7, 4]])  # second pair with mixed winding
     d = raster_ref.render_depth(verts, faces, T, K, 48, 64)
-    assert d.shape == (48, 64) and np.all(d > 0)
-    assert np.isclose(d[0, 0], 2.0) and np.isclose(d[24, 32], 1.0)
-    # the small quad covers |x|,|y| < 0.2 at z=1 -> 10 px around the principal point
-    assert (d == 1.0).sum() == 20 * 20
+    assert d.shape == (48, 64)
+    assert np.isclose(d[0, 0], 2.0) and np.isclose(d[24, 33], 1.0)
+    # the small quad covers |x|,|y| < 0.2 at z=1 -> 20 x 20 px around the principal point.  Its diagonal (the edge the two
+    # triangles share) runs exactly through 20 pixel centres: PyTorch3D's strict inside test gives those to NEITHER
+    # triangle, so the far quad shows through -- and the far quad's own diagonal leaves background (-1) along v = u - 8.
+    assert (d == 1.0).sum() == 20 * 20 - 20
+    ys, xs = np.mgrid[0:48, 0:64]
+    on_far_diagonal = ys == xs - 8
+    assert np.all(d[on_far_diagonal] == -1) and np.all(d[~on_far_diagonal] > 0)
+    assert d[24, 32] == -1  # on both diagonals
 
 
 def test_slanted_plane_is_perspective_correct_and_background():
@@ -31,3 +42,33 @@ def test_slanted_plane_is_perspective_correct_and_background():
     assert covered.any() and (~covered).any()
     np.testing.assert_allclose(d[covered], want[covered], rtol=1e-6)
     assert np.all(d[~covered] == -1)
+
+
+def _handcases():
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "raster_handcases.json")))
+
+
+@pytest.mark.parametrize("case", _handcases(), ids=lambda c: c["name"])
+def test_oracle_reproduces_hand_derived_pytorch3d_cases(case):
+    want = np.asarray(case["expected"], dtype=np.float64)
+    got = raster_ref.render_depth(np.asarray(case["verts"]), np.asarray(case["faces"]), np.asarray(case["cam_T_world"]),
+                                  np.asarray(case["K"]), case["h"], case["w"])
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got > 0, want > 0)  # coverage, including samples exactly on edges, bit for bit
+    assert int((want > 0).sum()) == case["covered"]
+    np.testing.assert_allclose(got[want > 0], want[want > 0], rtol=1e-6)
+    assert np.all(got[want < 0] == -1)
+
+
+def test_hand_case_fixture_is_what_the_derivation_script_writes(tmp_path):
+    """The committed fixture equals a fresh run of the derivation (exact rational arithmetic, no rasteriser involved)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_raster_handcases",
+                                                  os.path.join(os.path.dirname(__file__), "golden", "make_raster_handcases.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    committed = {c["name"]: c for c in _handcases()}
+    for c in mod.cases():
+        exp = [[float(v) for v in row] for row in mod.derive(c)]
+        assert exp == committed[c["name"]]["expected"], c["name"]
