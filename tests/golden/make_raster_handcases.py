@@ -31,7 +31,7 @@ Rules (pytorch3d 0.7.4):
      = 1 / sum_i (b_i / z_i).
  R5  visibility: faces_per_pixel=1 keeps the face with the smallest pz (> 0); a face whose three vertices are all behind
      the camera (zmax < 0) is skipped; pixels no face covers hold zbuf = -1.
- Not covered by these cases (stated deviation): faces that cross the camera plane.  PyTorch3D's
+ Not covered by these cases (stated deviation, DESIGN.md section 2, oracle table): faces that cross the camera plane.  PyTorch3D's
  z_clip_value is None for PerspectiveCameras (no znear), so it rasterises their wrapped-around projections; our renderer
  drops faces with a vertex nearer than 1 cm.
 """
