@@ -332,12 +332,16 @@ def main():
     graphs = None
     if args.graph:
         try:
-            for _ in range(3):  # allocator / weight-pack warm-up outside capture
-                model_step()
+            # allocator / weight-pack / per-stream conv scratch warm-up outside capture, ON the capture stream (the library
+            # keeps its cross-workgroup reduction scratch per stream and cannot allocate while the stream is capturing)
+            cap_stream = torch.cuda.Stream(device)
+            cap_stream.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(cap_stream):
+                for _ in range(3):
+                    model_step()
             torch.cuda.synchronize(device)
             pool = torch.cuda.graph_pool_handle()
             gs = [torch.cuda.CUDAGraph() for _ in range(3)]
-            cap_stream = torch.cuda.Stream(device)
             state = {"i": 0}
 
             def cut(tag):
