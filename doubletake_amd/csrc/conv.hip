@@ -671,7 +671,16 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
   const int ty = 2 * (gi >> 3) + (grp_a ? 0 : 1), tx = gi & 7;
 
   const int wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
-  long bid = xcd_contiguous_block(a.xcd_remap, vblock, vgrid);
+  // cross-workgroup K split, as in conv_mfma_body: workgroups [0, kplain) own a whole block, the others 1/P of one
+  const bool split_wg = a.kparts > 1 && vblock >= (unsigned)a.kplain;
+  const int kparts = split_wg ? a.kparts : 1;
+  long bid;
+  if (a.kparts <= 1) bid = xcd_contiguous_block(a.xcd_remap, vblock, vgrid);
+  else if (!split_wg) bid = xcd_contiguous_block(a.xcd_remap, vblock, (unsigned)a.kplain);
+  else bid = xcd_contiguous_block(a.xcd_remap, vblock - (unsigned)a.kplain, vgrid - (unsigned)a.kplain);
+  const int part = split_wg ? (int)(bid % kparts) : 0;
+  if (split_wg) bid = a.kplain + bid / kparts;
+  const long blk = bid - a.kplain;  // index into the partial-block scratch
   const int cb = (int)(bid % a.co_blocks);
   bid /= a.co_blocks;
   const int bx = (int)(bid % wt_x);
@@ -746,10 +755,11 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
 
   // every K-split group runs the same number of iterations so that the workgroup barriers line up; a group
   // whose share is exhausted stages zeros against (re-read, harmless) weights
-  const int iters = (a.groups + KSPLIT - 1) / KSPLIT;
-  if (ks < a.groups) DTW_PREFETCH(ks);
+  const int g_stride = KSPLIT * kparts, g_base = part * KSPLIT;
+  const int iters = (a.groups - g_base + g_stride - 1) / g_stride;
+  if (g_base + ks < a.groups) DTW_PREFETCH(g_base + ks);
   for (int i = 0; i < iters; ++i) {
-    const int g = ks + i * KSPLIT;
+    const int g = g_base + ks + i * g_stride;
     const bool live_g = g < a.groups;
     float* buf = lds + (i & 1) * kWinoPatchFloats;
 #pragma unroll
@@ -763,7 +773,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
 #pragma unroll
     for (int b = 0; b < 4; ++b) wc[b] = w[b];
     if (!(DT_WABL & 8)) __syncthreads();  // patch visible; everyone is done with this buffer from two iterations ago
-    if (g + KSPLIT < a.groups) DTW_PREFETCH(g + KSPLIT);
+    if (g + g_stride < a.groups) DTW_PREFETCH(g + g_stride);
     // B^T d B restricted to transform row `wave`
     float4 tcol[4];
 #pragma unroll
@@ -805,9 +815,11 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
   const bool in_image = oy < a.h_out && ox < a.w_out;
   const size_t pix_off = (((size_t)n * a.h_out + oy) * a.w_out + ox) * a.c_out;
   // the 4 channel quads of a tile are dealt to the KSPLIT groups
+  constexpr int NQ = 4 / KSPLIT;
+  float4 ov[NQ];
 #pragma unroll
-  for (int qi = 0; qi < 4 / KSPLIT; ++qi) {
-    const int qd = ks * (4 / KSPLIT) + qi;
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int qd = ks * NQ + qi;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k2 = 0; k2 < KSPLIT; ++k2) {
@@ -821,6 +833,37 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
         o.x += za.x - zbv.x - zc.x; o.y += za.y - zbv.y - zc.y; o.z += za.z - zbv.z - zc.z; o.w += za.w - zbv.w - zc.w;
       }
     }
+    ov[qi] = o;
+  }
+  if (kparts > 1) {  // (workgroup-uniform)
+    // publish this part's output block, count arrivals, the last workgroup sums the parts in part order (conv_mfma_body)
+    float4* slot = reinterpret_cast<float4*>(a.part_buf) + (size_t)blk * kparts * 1024 + threadIdx.x;
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) store_f4_coherent(slot + ((size_t)part * NQ + qi) * (256 * KSPLIT), ov[qi]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // all partial stores acknowledged; all reads of the Z values in lds_all are done
+    unsigned* flag = reinterpret_cast<unsigned*>(lds_all);
+    if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(a.part_cnt + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*reinterpret_cast<volatile unsigned*>(flag) != (unsigned)(kparts - 1)) return;
+    if (threadIdx.x == 0) __hip_atomic_store(a.part_cnt + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q2 = 0; q2 < kparts; ++q2) {
+        const float4 pv = (q2 == part) ? ov[qi] : load_f4_coherent(slot + ((size_t)q2 * NQ + qi) * (256 * KSPLIT));
+        sum.x = (q2 == 0) ? pv.x : sum.x + pv.x;
+        sum.y = (q2 == 0) ? pv.y : sum.y + pv.y;
+        sum.z = (q2 == 0) ? pv.z : sum.z + pv.z;
+        sum.w = (q2 == 0) ? pv.w : sum.w + pv.w;
+      }
+      ov[qi] = sum;
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int qd = ks * NQ + qi;
+    float4 o = ov[qi];
     if (in_image) {
       const int co = cb * 32 + qd * 8 + half * 4;
       const size_t off = pix_off + co;
@@ -1241,9 +1284,9 @@ static int conv_scratch(hipStream_t st, size_t part_floats, size_t counters, flo
 }
 
 // attach scratch at the given offsets (a pair launch gives its two convolutions disjoint slices)
-static int attach_scratch(hipStream_t st, ConvArgs* a, long blocks_a, ConvArgs* b, long blocks_b) {
+static int attach_scratch(hipStream_t st, ConvArgs* a, long blocks_a, ConvArgs* b, long blocks_b, size_t part_floats_a = 1024) {
   const long sa = (a && a->kparts > 1) ? blocks_a - a->kplain : 0, sb = (b && b->kparts > 1) ? blocks_b - b->kplain : 0;
-  const size_t fa = (size_t)sa * (a ? a->kparts : 0) * 1024, fb = (size_t)sb * (b ? b->kparts : 0) * 1024;
+  const size_t fa = (size_t)sa * (a ? a->kparts : 0) * part_floats_a, fb = (size_t)sb * (b ? b->kparts : 0) * 1024;
   if (fa + fb == 0) return 0;
   float* parts = nullptr;
   unsigned* cnt = nullptr;
@@ -1399,12 +1442,30 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
   // few output blocks (the 60x80 level and below): split K over two groups of four waves
   static const int force_split = [] { const char* e = getenv("DT_WINO_KSPLIT"); return e ? atoi(e) : 0; }();
   const int ksplit = force_split ? force_split : ((blocks < 256 && a.groups >= 8) ? 2 : 1);
+  // cross-workgroup K split (see plan_kparts): all parts when the P-fold workgroup count still fits one round of CUs,
+  // only the leftover blocks when the launch is slightly larger than the chip (300 blocks at 120x160)
+  static const int wino_parts = [] { const char* e = getenv("DT_WINO_KPARTS"); return e ? atoi(e) : -1; }();
+  const int cus = device_cus();
+  if (wino_parts != 0 && ksplit <= 2) {
+    if (blocks > cus && blocks < 2L * cus && cus % 8 == 0) {
+      const long rest = blocks - cus;
+      const int P = (rest * 4 <= cus + cus / 4) ? 4 : 2;
+      if (a.groups >= ksplit * P * 2) {
+        a.kparts = P;
+        a.kplain = cus;
+      }
+    } else if (wino_parts > 1 && blocks * wino_parts <= cus && a.groups >= ksplit * wino_parts * 2) {
+      a.kparts = wino_parts;
+    }
+  }
+  const long grid = a.kplain + (blocks - a.kplain) * a.kparts;
+  if (int rc = attach_scratch(to_stream(s), &a, blocks, nullptr, 0, 4096)) return rc;
   if (ksplit == 4)
-    hipLaunchKernelGGL(conv_wino_kernel<4>, dim3((unsigned)blocks), dim3(1024), 0, to_stream(s), a);
+    hipLaunchKernelGGL(conv_wino_kernel<4>, dim3((unsigned)grid), dim3(1024), 0, to_stream(s), a);
   else if (ksplit == 2)
-    hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)blocks), dim3(512), 0, to_stream(s), a);
+    hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)grid), dim3(512), 0, to_stream(s), a);
   else
-    hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, to_stream(s), a);
+    hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)grid), dim3(256), 0, to_stream(s), a);
   return check_launch("dt_conv2d_wino_f32");
 }
 

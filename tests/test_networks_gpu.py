@@ -261,6 +261,8 @@ def test_batched_conv_graph_equals_per_sample():
     (1, 16, 32, 13, 21, "zeros", 1, False),     # ragged extent, one source
     (2, 24, 64, 16, 32, "zeros", 2, True),      # two sources, the second nearest-upsampled, residual + bias
     (1, 64, 32, 24, 40, "replicate", 1, False),  # replicate padding
+    (1, 64, 64, 120, 160, "zeros", 1, True),    # 300 blocks on 256 CUs: tail split (256 whole blocks + 44 x 4 quarter workgroups)
+    (1, 128, 64, 120, 160, "zeros", 2, True),   # the same with two sources (one nearest-upsampled)
 ])
 def test_winograd_conv_vs_direct(shape):
     """conv_wino_kernel (F(2x2,3x3) on MFMA) against the direct one-thread-per-output conv."""
@@ -282,7 +284,10 @@ def test_winograd_conv_vs_direct(shape):
     want = ops.conv2d(srcs, conv, act=ops.ACT_LRELU02, residual=res, impl="simple")
     got = ops.conv2d(srcs, conv, act=ops.ACT_LRELU02, residual=res, impl="wino")
     assert got.shape == want.shape
-    assert (got - want).abs().max().item() < 2e-5
+    # fp32 Winograd vs fp32 direct: a few ulp of the largest output (2e-5 absolute for the O(1) outputs of the small cases)
+    assert (got - want).abs().max().item() < 4e-6 * max(want.abs().max().item(), 5.0)
+    again = ops.conv2d(srcs, conv, act=ops.ACT_LRELU02, residual=res, impl="wino")
+    assert torch.equal(got, again)  # the cross-workgroup reduction sums in part order: run-to-run bit equality
 
 
 @pytest.mark.parametrize("cin,cout,stride,h,w", [
@@ -294,7 +299,7 @@ def test_winograd_conv_vs_direct(shape):
     (256, 384, 2, 30, 40),
     (24, 32, 1, 10, 12),      # small shapes: combinations without a common workgroup size fall back to two launches
 ])
-def test_paired_conv_launch_equals_two_launches_bitwise(cin, cout, stride, h, w):
+def test_paired_conv_launch_equals_two_launches(cin, cout, stride, h, w):
     """BasicBlock's conv1 + shortcut conv in one launch (dt_conv2d_pair_f32) against the two separate launches."""
     import gpu_util as gu
     from doubletake_amd.modules import conv_ops as ops
@@ -310,13 +315,14 @@ def test_paired_conv_launch_equals_two_launches_bitwise(cin, cout, stride, h, w)
     a2 = ops.conv2d(srcs, blk.conv1, act=ops.ACT_LRELU02)
     b2 = ops.conv2d(srcs, blk.downsample[0], act=ops.ACT_NONE)
     torch.cuda.synchronize()
-    if h * w > 30 * 40 or h * w < 15 * 20:
+    if h * w > 120 * 160 or h * w < 15 * 20:
         assert torch.equal(a1, a2) and torch.equal(b1, b2)
     else:
-        # the low-resolution levels: the K split across waves / workgroups is planned per LAUNCH (a pair shares the CUs
-        # between its two convolutions), i.e. the two paths may sum the same fp32 products in a different order
-        assert (a1 - a2).abs().max().item() < 2e-5
-        assert (b1 - b2).abs().max().item() < 2e-5
+        # the K split across waves / workgroups is planned per LAUNCH (a pair shares the CUs between its two
+        # convolutions; a lone 300-block launch splits its leftover blocks), i.e. the two paths may sum the same fp32
+        # products in a different order
+        assert (a1 - a2).abs().max().item() < 4e-6 * max(a2.abs().max().item(), 5.0)
+        assert (b1 - b2).abs().max().item() < 4e-6 * max(b2.abs().max().item(), 5.0)
     assert a1.abs().max().item() > 0.01 and b1.abs().max().item() > 0.01
     # same launch twice: bit-identical (the cross-workgroup reduction sums in part order, not in arrival order)
     a3, b3 = ops.conv2d_pair(srcs, blk.conv1, ops.ACT_LRELU02, blk.downsample[0], ops.ACT_NONE)
