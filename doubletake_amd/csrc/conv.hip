@@ -1454,8 +1454,14 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
         a.kparts = P;
         a.kplain = cus;
       }
-    } else if (wino_parts > 1 && blocks * wino_parts <= cus && a.groups >= ksplit * wino_parts * 2) {
-      a.kparts = wino_parts;
+    } else if (blocks < cus) {
+      // few blocks (the 30x40 level: 96): the largest P that still fits one round and leaves every part >= 2 K groups
+      for (int P = 4; P >= 2; P /= 2) {
+        if ((wino_parts < 0 || P <= wino_parts) && blocks * P <= cus && a.groups >= ksplit * P * 2) {
+          a.kparts = P;
+          break;
+        }
+      }
     }
   }
   const long grid = a.kplain + (blocks - a.kplain) * a.kparts;
@@ -1537,7 +1543,20 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
       const long pix_blocks = ((long)b.n * b.h_out * b.w_out + 31) / 32;
       DT_PAIR(WinoBody<1>, OneByOneBody, blocks_a, (pix_blocks * b.co_blocks + 3) / 4);
     }
-    if (ksplit == 2 && (pb == PICK_1X1_SPLIT8 || pb == PICK_1X1_SPLIT16)) DT_PAIR(WinoBody<2>, M118, blocks_a, blocks_b);
+    if (ksplit == 2 && (pb == PICK_1X1_SPLIT8 || pb == PICK_1X1_SPLIT16)) {
+      // few Winograd blocks (the 30x40 level): split their K over workgroups as the single launch does; the light 1x1
+      // workgroups fill in behind them
+      static const int wino_parts = [] { const char* e = getenv("DT_WINO_KPARTS"); return e ? atoi(e) : -1; }();
+      const int cus = device_cus();
+      if (wino_parts != 0 && blocks_a < cus)
+        for (int P = 4; P >= 2; P /= 2)
+          if ((wino_parts < 0 || P <= wino_parts) && blocks_a * P <= cus && a.groups >= ksplit * P * 2) {
+            a.kparts = P;
+            break;
+          }
+      if (int rc = attach_scratch(st, &a, blocks_a, nullptr, 0, 4096)) return rc;
+      DT_PAIR(WinoBody<2>, M118, blocks_a * a.kparts, blocks_b);
+    }
   } else {
     const long blocks_a = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
     const ConvPick pa = pick_direct(a, da);

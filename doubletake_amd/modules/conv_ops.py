@@ -99,8 +99,9 @@ def packed_weight_wino(conv: nn.Conv2d, device):
 
 
 #: use the Winograd kernel for 3x3 stride-1 layers with at least this many 8x16-pixel x 32-channel workgroups
-#: (set by measurement); DT_CONV_WINO_MIN_BLOCKS overrides, 0 disables
-WINO_MIN_BLOCKS = int(_os.environ.get("DT_CONV_WINO_MIN_BLOCKS", "128"))
+#: (set by measurement, see DESIGN.md section 4.2: 96 = down to the 30x40 level, whose 96 blocks run as 2 workgroups each;
+#: 48 = the 15x20 level too measured slower); DT_CONV_WINO_MIN_BLOCKS overrides, 0 disables
+WINO_MIN_BLOCKS = int(_os.environ.get("DT_CONV_WINO_MIN_BLOCKS", "96"))
 
 
 def _dev_param(conv, name, device):
