@@ -1235,7 +1235,7 @@ static void plan_kparts(const KSeg* seg, int nseg, int* P) {
   for (int i = 0; i < nseg && i < 2; ++i) P[i] = it->second[(size_t)i];
 }
 
-// Scratch of the cross-workgroup reduction: one per (device, stream), grown on demand, never shrunk.  Launches on one stream
+// Scratch of the cross-workgroup reduction: one per (device, stream), grown on demand, never shrunk or freed.  Launches on one stream
 // are ordered, so consecutive layers reuse it; the counters are zero whenever no launch is in flight (the last workgroup to
 // arrive at a block resets its counter).  Two host threads driving the SAME stream concurrently are not supported.
 struct ConvScratch {
@@ -1245,6 +1245,7 @@ struct ConvScratch {
 };
 static std::mutex g_scratch_mutex;
 static std::map<std::pair<int, hipStream_t>, ConvScratch> g_scratch;
+static std::vector<void*> g_retired;
 
 static int conv_scratch(hipStream_t st, size_t part_floats, size_t counters, float** parts, unsigned** cnt) {
   int dev = 0;
@@ -1255,14 +1256,11 @@ static int conv_scratch(hipStream_t st, size_t part_floats, size_t counters, flo
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   ConvScratch& ws = g_scratch[std::make_pair(dev, st)];
   if (ws.part_floats < part_floats || ws.counters < counters) {
-    // growing: earlier launches on this stream may still use the old buffers
+    // growing: earlier launches on this stream -- or hipGraphs captured from it -- may still use the old buffers, so they
+    // are retired, not freed (a few MB per growth step; the sizes below make growth rare)
     if (ws.parts || ws.cnt) {
-      if (hipStreamSynchronize(st) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail("conv scratch: cannot synchronise the stream before growing (stream capture in progress?)");
-      }
-      (void)hipFree(ws.parts);
-      (void)hipFree(ws.cnt);
+      g_retired.push_back(ws.parts);
+      g_retired.push_back(ws.cnt);
       ws = ConvScratch();
     }
     const size_t pf = part_floats > (size_t)(4u << 20) ? part_floats : (size_t)(4u << 20);  // >= 16 MB
@@ -1273,7 +1271,9 @@ static int conv_scratch(hipStream_t st, size_t part_floats, size_t counters, flo
       (void)hipFree(ws.parts);
       (void)hipFree(ws.cnt);
       ws = ConvScratch();
-      return fail("conv scratch: cannot allocate %zu + %zu bytes", pf * sizeof(float), nc * sizeof(unsigned));
+      return fail("conv scratch: cannot allocate %zu + %zu bytes (if this stream is being captured into a hipGraph, run the "
+                  "layer on it once before the capture: the scratch is allocated on first use)",
+                  pf * sizeof(float), nc * sizeof(unsigned));
     }
     ws.part_floats = pf;
     ws.counters = nc;
