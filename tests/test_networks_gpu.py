@@ -375,3 +375,51 @@ def test_low_resolution_conv_tiling_and_cross_workgroup_split(case):
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o, got)
+
+
+def _random_conv_cases(n_cases=28, seed=20260927):
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < n_cases:
+        k = int(rng.choice([1, 3, 3, 3]))
+        st = int(rng.choice([1, 1, 2])) if k == 3 else 1
+        n = int(rng.choice([1, 1, 2, 3]))
+        h, w = 2 * int(rng.randint(3, 21)), 2 * int(rng.randint(3, 21))  # even: an upsampled source needs it
+        if rng.rand() < 0.3:
+            h, w = h + 1, w + 1  # odd extents (then no upsampled source)
+        cout = 32 * int(rng.randint(1, 13))
+        nsrc = int(rng.choice([1, 1, 2, 3]))
+        chans = [8 * int(rng.randint(1, 40)) for _ in range(nsrc)]
+        ups = [bool(rng.rand() < 0.4) and h % 2 == 0 and w % 2 == 0 for _ in range(nsrc)]
+        cases.append(dict(k=k, st=st, n=n, h=h, w=w, cout=cout, chans=chans, ups=ups, pad=str(rng.choice(["zeros", "replicate"])),
+                          res=bool(rng.rand() < 0.5), act=int(rng.choice([0, 1, 2, 3])), seed=int(rng.randint(1, 1 << 20))))
+    return cases
+
+
+@pytest.mark.parametrize("c", _random_conv_cases(), ids=lambda c: f"k{c['k']}s{c['st']}_n{c['n']}_{c['h']}x{c['w']}_{'+'.join(map(str, c['chans']))}to{c['cout']}")
+def test_conv_random_shapes_vs_direct(c):
+    """Seeded sweep over shapes the planner routes differently (direct / Winograd, in-workgroup and cross-workgroup K split,
+    transposed tiling, tail split, batch > 1, one to three sources with nearest-upsampled ones, both paddings, residual,
+    every activation): the product path against the one-thread-per-output direct kernel, and run-to-run bit equality."""
+    import gpu_util as gu
+    from doubletake_amd.modules import conv_ops as ops
+
+    cin = sum(c["chans"])
+    conv = torch.nn.Conv2d(cin, c["cout"], c["k"], stride=c["st"], padding=c["k"] // 2, padding_mode=c["pad"]).to(gu.dev())
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(syn.hash_normalish(tuple(conv.weight.shape), c["seed"]) * (1.0 / (cin * c["k"] ** 2)) ** 0.5))
+        conv.bias.copy_(torch.from_numpy(syn.hash_normalish((c["cout"],), c["seed"] + 1) * 0.1))
+    srcs = []
+    for i, (ch, up) in enumerate(zip(c["chans"], c["ups"])):
+        hh, ww = (c["h"] // 2, c["w"] // 2) if up else (c["h"], c["w"])
+        srcs.append((ops.as_nhwc(_t(syn.hash_normalish((c["n"], ch, hh, ww), c["seed"] + 10 + i))), up))
+    ho = (c["h"] + 2 * (c["k"] // 2) - c["k"]) // c["st"] + 1
+    wo = (c["w"] + 2 * (c["k"] // 2) - c["k"]) // c["st"] + 1
+    res = ops.as_nhwc(_t(syn.hash_normalish((c["n"], c["cout"], ho, wo), c["seed"] + 20))) if c["res"] else None
+    want = ops.conv2d(srcs, conv, act=c["act"], residual=res, impl="simple")
+    got = ops.conv2d(srcs, conv, act=c["act"], residual=res)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (c["n"], c["cout"], ho, wo)
+    assert (got - want).abs().max().item() < 4e-6 * max(want.abs().max().item(), 5.0)
+    assert got.abs().max().item() > 0.05
+    assert torch.equal(ops.conv2d(srcs, conv, act=c["act"], residual=res), got)
