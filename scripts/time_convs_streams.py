@@ -46,6 +46,32 @@ def main():
                 frame()
         torch.cuda.synchronize()
         out[f"streams_{S}_ms_per_frame"] = (time.perf_counter() - t0) / n * 1e3
+    # the same with one hipGraph per stream (no host issue limit): the GPU-side overlap of S conv stacks
+    for S in (1, 2, 3):
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        graphs = []
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    frame()  # per-stream scratch / allocator warm-up before capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                keep = frame()
+            graphs.append((g, keep))
+        torch.cuda.synchronize()
+        n = 240
+        for i in range(12):
+            with torch.cuda.stream(streams[i % S]):
+                graphs[i % S][0].replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            with torch.cuda.stream(streams[i % S]):
+                graphs[i % S][0].replay()
+        torch.cuda.synchronize()
+        out[f"graph_streams_{S}_ms_per_frame"] = (time.perf_counter() - t0) / n * 1e3
     print(json.dumps(out))
 
 
