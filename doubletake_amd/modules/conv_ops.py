@@ -75,8 +75,18 @@ def packed_weight(conv: nn.Conv2d, device, transposed=False):
 TRANSPOSED_TILING = _os.environ.get("DT_CONV_TRANSPOSE", "1") != "0"
 
 
+_TRANSPOSE_MEMO = {}
+
+
 def _want_transposed(L, d) -> bool:
-    return bool(TRANSPOSED_TILING and L.dt_conv_transposed_tiling(C.byref(d)))
+    """dt_conv_transposed_tiling(d), memoised on the launch shape (one ctypes call less per conv launch)."""
+    if not TRANSPOSED_TILING:
+        return False
+    key = (d.n, d.h_out, d.w_out, d.c_out, d.nsrc, d.c[0], d.c[1], d.c[2], d.ksize, d.stride)
+    hit = _TRANSPOSE_MEMO.get(key)
+    if hit is None:
+        hit = _TRANSPOSE_MEMO[key] = bool(L.dt_conv_transposed_tiling(C.byref(d)))
+    return hit
 
 
 def packed_weight_wino(conv: nn.Conv2d, device):
