@@ -77,9 +77,11 @@ def build_model(device):
 def cpu_baseline(inp, pyr, model, threads="8,all", batched=False):
     """the torch-CPU restatement of the path (oracle/torch_cpu_ref.py: the ATen ops the
     reference composes, in its loop-over-planes order) on the SAME frame the GPU steps process -- mesh-hint volume,
-    lowest cost, CVEncoder, SkipDecoderRegression, exp -- timed on this box's host cores: torch.set_num_threads(all
-    physical cores) and 8 (the survey container's count), one warm-up then the median of the
-    timed runs; the batched (Fast-manager) volume once for comparison.  Returns (dict for the JSON line, depth maps)."""
+    lowest cost, CVEncoder, SkipDecoderRegression, exp -- timed on this box's host cores with torch.set_num_threads(8)
+    (the survey container's count) and with every physical core.  Bounded to about 25 s of CPU
+    work: one whole frame first (warm-up, parity depths, cross-check), then the plane loop over every 4th plane (5 runs,
+    median; one run at the other thread counts) and the conv part (3 runs); the batched (Fast-manager) volume once on
+    request.  Returns (dict for the JSON line, depth maps)."""
     import torch
     from oracle import torch_cpu_ref as tref
 
@@ -104,33 +106,38 @@ def cpu_baseline(inp, pyr, model, threads="8,all", batched=False):
            t["max_depth"], CFG["planes"], lin("cost_volume.mlp"))
     cve_p, dec_p = sub("cost_volume_net."), sub("depth_decoder.")
 
-    def frame(volume_fn):
+    def volume(plane_ids=None):
         t0 = time.perf_counter()
-        vol, planes = volume_fn(*geo, hint=hint, hint_mlp=lin("cost_volume.hint_mlp"))
-        t1 = time.perf_counter()
+        vol, planes = tref.hint_volume_loop(*geo, hint=hint, hint_mlp=lin("cost_volume.hint_mlp"), plane_ids=plane_ids)
+        return time.perf_counter() - t0, vol, planes
+
+    def rest(vol, planes):
+        t0 = time.perf_counter()
         tref.lowest_cost(vol, planes)
         out = tref.skip_decoder_regression([pyr_t[0]] + tref.cv_encoder(vol, pyr_t[1:], cve_p), dec_p)
         depths = {k.replace("log_", ""): torch.exp(v).numpy() for k, v in out.items() if k.startswith("log_depth")}
-        t2 = time.perf_counter()
-        return t2 - t0, t1 - t0, depths
+        return time.perf_counter() - t0, depths
 
+    # Bounded sample (about 25 s of CPU work instead of 95 s for full-frame repeats): ONE whole frame at 8 threads -- warm-up,
+    # the depth maps of the parity check, and a cross-check of the estimate -- then the volume loop over every
+    # SAMPLE_STRIDE-th plane (all planes run the same ops on the same shapes) 5 times at 8 threads (median) and once with
+    # every physical core, and the conv part (lowest cost, CVEncoder, decoder, exp) 3 times.  frame = stride x sample + rest.
+    SAMPLE_STRIDE = 4
+    sample_ids = list(range(0, CFG["planes"], SAMPLE_STRIDE))
+    scale = CFG["planes"] / float(len(sample_ids))
     prev = torch.get_num_threads()
+    torch.set_num_threads(8)
+    v_full, vol, planes = volume()
+    r_full, depths = rest(vol, planes)
+    rest_ts = sorted(rest(vol, planes)[0] for _ in range(3))
+    rest_s = rest_ts[1]
     runs = {}
-    depths = None
-    # 8 threads (the count BASELINE.md section 2 was measured with, and on a many-core box the faster setting: the
-    # per-plane ops are small, so all-core runs lose to synchronisation) gets the full protocol; other counts are
-    # confirmation points of 2 timed runs so that the default bench stays within a few minutes
-    plan = [(8, 5)] + [(n, 2) for n in thread_counts if n != 8]
+    plan = [(8, 5)] + [(n, 1) for n in thread_counts if n != 8]
     for nt, n_timed in plan:
         torch.set_num_threads(nt)
-        if nt == 8:
-            frame(tref.hint_volume_loop)  # warm-up
-        ts = []
-        for _ in range(n_timed):
-            sec, vsec, depths = frame(tref.hint_volume_loop)
-            ts.append((sec, vsec))
-        ts.sort()
-        runs[nt] = dict(frame_s=ts[len(ts) // 2][0], volume_s=ts[len(ts) // 2][1], timed_runs=n_timed)
+        ts = sorted(volume(sample_ids)[0] for _ in range(n_timed))
+        vs = ts[len(ts) // 2] * scale
+        runs[nt] = dict(frame_s=vs + rest_s, volume_s=vs, timed_runs=n_timed)
     best = min(runs, key=lambda n: runs[n]["frame_s"])
     batched_s = None
     if batched:
@@ -139,8 +146,8 @@ def cpu_baseline(inp, pyr, model, threads="8,all", batched=False):
         tref.hint_volume_batched(*geo, hint=hint, hint_mlp=lin("cost_volume.hint_mlp"))
         batched_s = time.perf_counter() - t0
     torch.set_num_threads(prev)
-    per = "; ".join(f"{n} threads: frame {r['frame_s']:.2f} s (volume {r['volume_s']:.2f} s), median of {r['timed_runs']}"
-                    for n, r in runs.items())
+    per = "; ".join(f"{n} threads: frame {r['frame_s']:.2f} s (volume {r['volume_s']:.2f} s), "
+                    f"{'median of ' + str(r['timed_runs']) if r['timed_runs'] > 1 else 'one run'}" for n, r in runs.items())
     res = {
         "value": 1.0 / runs[best]["frame_s"],
         "unit": "frames/s",
@@ -150,11 +157,14 @@ def cpu_baseline(inp, pyr, model, threads="8,all", batched=False):
         "physical_cores": phys,
         "frames_per_s_by_threads": {str(n): 1.0 / r["frame_s"] for n, r in runs.items()},
         "volume_batched_s": batched_s,
-        "sample": f"whole frames of the same workload (mesh-hint volume looped over 64 planes + lowest cost + CVEncoder + "
-                  f"SkipDecoderRegression + exp) through the torch-CPU restatement oracle/torch_cpu_ref.py, fp32, on {cpu_model}: "
-                  f"{per} (one warm-up frame first); " + (f"batched (Fast-manager) volume alone at {best} threads: {batched_s:.2f} s; "
-                                                           if batched_s is not None else "") + "value = best setting. "
-                  f"Sanity anchor: the reference itself measured 4.93 s (volume) + 0.12 s (convs) per frame on 8 vCPUs (BASELINE.md 2)",
+        "sample": f"the same frame the GPU steps process (mesh-hint volume looped over the planes + lowest cost + CVEncoder + "
+                  f"SkipDecoderRegression + exp) through the torch-CPU restatement oracle/torch_cpu_ref.py, fp32, on {cpu_model}; "
+                  f"bounded sample: volume loop over every {SAMPLE_STRIDE}th of the {CFG['planes']} planes (x{scale:g}) + the conv part "
+                  f"({rest_s:.2f} s, median of 3): {per}; cross-check: the one whole frame run first at 8 threads (cold) took "
+                  f"{v_full + r_full:.2f} s (volume {v_full:.2f} s); " + (f"batched (Fast-manager) volume alone at {best} threads: "
+                                                                          f"{batched_s:.2f} s; " if batched_s is not None else "")
+                  + "value = best setting.  Sanity anchor: the reference itself measured 4.93 s (volume) + 0.12 s (convs) per "
+                    "frame on 8 vCPUs (BASELINE.md 2)",
     }
     return res, depths
 

@@ -105,16 +105,19 @@ def _common(cur, src, src_ext, src_poses, src_Ks, cur_invK):
 
 
 @torch.no_grad()
-def hint_volume_loop(cur, src, src_ext, src_poses, src_Ks, cur_invK, min_depth, max_depth, D, mlp, hint=None, hint_mlp=None):
+def hint_volume_loop(cur, src, src_ext, src_poses, src_Ks, cur_invK, min_depth, max_depth, D, mlp, hint=None, hint_mlp=None,
+                     plane_ids=None):
     """Loop over planes (reference slow manager).  hint=None -> FeatureVolumeManager
-    (modules/feature_volume.py:81-356).  Returns (volume [b,D,h,w], planes [b,D])."""
+    (modules/feature_volume.py:81-356).  Returns (volume [b,D,h,w], planes [b,D]).
+    plane_ids: evaluate only these planes of the D (bench.py's bounded CPU-baseline sample: every plane costs the same ops);
+    the returned volume then has len(plane_ids) planes."""
     b, k, c, h, w, P, rays, tsrc, pose_feats = _common(cur, src, src_ext, src_poses, src_Ks, cur_invK)
     planes = depth_planes(min_depth, max_depth, D, b)
     src_B = src.reshape(b * k, c, h, w)
     if hint is not None:
         hd, hw, hm = _hint_maps(hint, h, w)
     out = []
-    for d in range(D):
+    for d in (range(D) if plane_ids is None else plane_ids):
         feats, _, _ = _plane_features(cur, src_B, P, rays, planes[:, d], tsrc, pose_feats, b, k, c, h, w)
         s = _mlp(feats, mlp)                                                 # [b,h,w,1]
         if hint is not None:
