@@ -127,12 +127,44 @@ def lib():
     except Exception:
         pass
     L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    ns = _Lib(L)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    _lib = L
-    return L
+        # entry points whose last argument is the stream launch kernels: give them the device guard
+        setattr(ns, name, _guarded(fn) if args and args[-1] is _P and name not in _NO_STREAM else fn)
+    _lib = ns
+    return ns
+
+
+class _Lib:
+    """Namespace of the bound entry points (``lib().dt_conv2d_f32(...)``); ``.cdll`` is the ctypes library."""
+
+    def __init__(self, cdll):
+        self.cdll = cdll
+
+
+class _ForeignStream(C.c_void_p):
+    """Stream handle of a GPU that is not HIP's current device (carries the device index for the launch guard)."""
+    device_index = None
+
+
+#: entry points whose trailing void* is a data pointer, not a stream
+_NO_STREAM = frozenset()
+
+
+def _guarded(fn):
+    def call(*args):
+        s = args[-1]
+        if type(s) is _ForeignStream:
+            with device_guard(s.device_index):
+                return fn(*args)
+        return fn(*args)
+
+    call.__name__ = fn.__name__
+    call.restype, call.argtypes = fn.restype, fn.argtypes
+    return call
 
 
 def check(rc, what=""):
@@ -147,13 +179,77 @@ def ptr(t):
 
 
 def current_stream(device=None):
-    """HIP stream handle of torch's current stream on ``device``.  The library launches on that stream without a device
-    guard of its own, so HIP's current device is switched to ``device`` here if it differs (one process per GPU is the
-    intended deployment; this keeps a single process that touches several GPUs correct as well)."""
+    """HIP stream handle of torch's current stream on ``device``.  No side effects: when ``device`` is not HIP's current
+    device the handle remembers it, and the entry point it is passed to runs under ``device_guard`` (the library
+    launches on the *current* device), restoring the caller's device afterwards."""
     import torch
 
+    handle = torch.cuda.current_stream(device).cuda_stream
     if device is not None:
         idx = torch.device(device).index
         if idx is not None and idx != torch.cuda.current_device():
-            torch.cuda.set_device(idx)
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            s = _ForeignStream(handle)
+            s.device_index = idx
+            return s
+    return C.c_void_p(handle)
+
+
+class device_guard:
+    """``with device_guard(t.device): launch(...)`` -- the library launches on HIP's *current* device (it takes a stream,
+    not a device id), so a call with tensors of another GPU switches to that GPU for the duration of the call and
+    restores the caller's current device afterwards (the switch used to be permanent).  A no-op -- no HIP
+    calls at all -- in the intended one-process-per-GPU deployment, where the tensors' device is the current one."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        import torch
+
+        idx = device if isinstance(device, int) else (torch.device(device).index if device is not None else None)
+        self.idx = idx
+        self.prev = None
+        if idx is not None:
+            cur = torch.cuda.current_device()
+            if cur != idx:
+                self.prev = cur
+
+    def __enter__(self):
+        if self.prev is not None:
+            import torch
+
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            import torch
+
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def record_ready(device):
+    """Token kept next to a cached device buffer that a kernel enqueued on the *current* stream is still filling
+    (weight packs).  ``wait_ready(token, device)`` on a later cache hit orders another stream behind that kernel."""
+    import torch
+
+    st = torch.cuda.current_stream(device)
+    ev = torch.cuda.Event()
+    ev.record(st)
+    return [ev, st.cuda_stream]
+
+
+def wait_ready(token, device):
+    """Cache hit: if the producer kernel of the buffer has not completed and the current stream is not the one it was
+    enqueued on, make the current stream wait for it.  Free once the producer is done (the token is cleared)."""
+    ev = token[0]
+    if ev is None:
+        return
+    import torch
+
+    if ev.query():
+        token[0] = None
+        return
+    cur = torch.cuda.current_stream(device)
+    if cur.cuda_stream != token[1]:
+        cur.wait_event(ev)

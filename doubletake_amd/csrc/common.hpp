@@ -21,6 +21,9 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t to_stream(dt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// compute units of HIP's CURRENT device (cached per device id: one process may drive several GPUs); 256 if unknown
+int device_cu_count();
+
 #define DT_REQUIRE(cond, ...)            \
   do {                                   \
     if (!(cond)) return dt::fail(__VA_ARGS__); \

@@ -1141,18 +1141,7 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
 }
 
 // ---- cross-workgroup K split: policy and workspace ---------------------------------------------------------------------
-static int device_cus() {
-  static int cus = 0;
-  if (cus <= 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
-      (void)hipGetLastError();
-      n = 256;
-    }
-    cus = n;
-  }
-  return cus;
-}
+static int device_cus() { return device_cu_count(); }
 
 // Number of workgroups P that share one output block of a K-split kernel.  Measured on the K-split kernels
 // (scripts/conv_quantisation.py, profiles/r2p_conv_quantisation.txt): a launch lasts about
@@ -1198,8 +1187,8 @@ static void plan_kparts(const KSeg* seg, int nseg, int* P) {
       if (seg[i].can_split && seg[i].groups >= seg[i].split * forced) P[i] = forced;
     return;
   }
-  // memo: the plan depends only on the launch shape
-  typedef std::array<long, 8> Key;
+  // memo: the plan depends only on the launch shape and the CU count of the device it runs on
+  typedef std::array<long, 9> Key;
   static std::mutex mtx;
   static std::map<Key, std::array<int, 2>> memo;
   Key key{};
@@ -1209,10 +1198,11 @@ static void plan_kparts(const KSeg* seg, int nseg, int* P) {
     key[(size_t)i * 4 + 2] = seg[i].split * 2 + (seg[i].can_split ? 1 : 0);
     key[(size_t)i * 4 + 3] = seg[i].ksize;
   }
+  const int cus = device_cus();
+  key[8] = cus;
   std::lock_guard<std::mutex> lock(mtx);
   auto it = memo.find(key);
   if (it == memo.end()) {
-    const int cus = device_cus();
     std::array<int, 2> best = {1, 1};
     int cand[2] = {1, 1};
     double best_cost = launch_cost_us(seg, cand, nseg, cus);
@@ -1495,7 +1485,8 @@ static ConvPick pick_direct(const ConvArgs& a, const dt_conv_desc* d) {
 /* conv1 and the shortcut conv of a BasicBlock (modules/layers.py:77-94) in ONE launch: both read the same sources.
  * A: 3x3 (stride 1 or 2), packed for the Winograd kernel when a_wino != 0 (stride 1 only) else for the direct kernel;
  * B: 1x1 stride 1 (when A has stride 1) or 3x3 stride 2 (when A has stride 2), direct packing.  Combinations whose two
- * kernels do not share a workgroup size fall back to two launches inside this call (same results either way). */
+ * kernels do not share a workgroup size fall back to two launches inside this call (same products either way; the fp32
+ * summation order may differ because the pair plans its K splits jointly). */
 int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const float* in0, const float* in1, const float* in2,
                        const float* packed_wa, int a_wino, const float* bias_a, float* out_a, const float* packed_wb,
                        const float* bias_b, float* out_b, dt_stream_t s) {
@@ -1524,7 +1515,8 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
                        (unsigned)(NA));                                                                                   \
     return check_launch("dt_conv2d_pair_f32");                                                                            \
   } while (0)
-  // direct 3x3 K-split bodies: same cross-workgroup split as the single launch would choose (bit-equal results)
+  // direct 3x3 K-split bodies: the two segments are planned jointly (plan_kparts with nseg = 2), so the split -- and with it
+  // the fp32 summation order -- can differ from what a lone launch of either convolution would choose
 #define DT_PAIR_KP(BA, BB, SPLIT_A, SPLIT_B)                                                                              \
   do {                                                                                                                    \
     const KSeg seg[2] = {{blocks_a, a.groups, SPLIT_A, 3, true}, {blocks_b, b.groups, SPLIT_B, db->ksize, true}};          \

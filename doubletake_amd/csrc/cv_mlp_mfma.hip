@@ -479,17 +479,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
 
 // waves per workgroup of the fused kernel (4 = one per SIMD, 8 = two per SIMD); DT_MLP_WAVES overrides
 static int g_mlp_waves = [] { const char* e = getenv("DT_MLP_WAVES"); return (e && e[0] == '4') ? 4 : 8; }();
-static int g_num_cus = 0;
-static int num_cus() {
-  if (g_num_cus > 0) return g_num_cus;
-  int dev = 0, n = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
-    (void)hipGetLastError();
-    n = 256;
-  }
-  g_num_cus = n;
-  return n;
-}
+static int num_cus() { return device_cu_count(); }
 
 }  // namespace dt
 

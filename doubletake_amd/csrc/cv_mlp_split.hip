@@ -436,17 +436,7 @@ __global__ __launch_bounds__(512, 2) void cv_mlp_split_kernel(const Args a) {
   }
 }
 
-static int g_cus = 0;
-static int num_cus() {
-  if (g_cus > 0) return g_cus;
-  int dev = 0, n = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
-    (void)hipGetLastError();
-    n = 256;
-  }
-  g_cus = n;
-  return n;
-}
+static int num_cus() { return dt::device_cu_count(); }
 
 }  // namespace sp
 }  // namespace dt

@@ -486,11 +486,7 @@ int dt_stem_conv_f32(const float* image_nchw, const float* packed_w, const float
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long tiles = (long)n * ((Ho + 3) / 4) * ((Wo + 7) / 8);
   const long pairs = (tiles + 1) / 2;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = dt::device_cu_count();
   const long want = (long)cus * 3;  // 148 VGPRs -> three workgroups per CU
   hipLaunchKernelGGL(dt::stem_conv_kernel, dim3((unsigned)(pairs < want ? pairs : want)), dim3(256), 0, dt::to_stream(s),
                      image_nchw, packed_w, bias64, out_nhwc, n, H, W, Ho, Wo, act);

@@ -233,7 +233,6 @@ __global__ __launch_bounds__(256) void head_mlp_multi_kernel(const HeadMultiArgs
     head_split_body<8>(a, tile, hbuf, red);
 }
 
-static int g_head_cus = 0;
 constexpr long kHeadSplitMaxTiles = 1024;
 
 }  // namespace dt
@@ -255,14 +254,7 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
   DT_REQUIRE(in_nhwc && wa && wb && tail && out, "dt_head_mlp_f32: null pointer");
   DT_REQUIRE(pixels > 0, "dt_head_mlp_f32: pixels=%ld", (long)pixels);
   DT_REQUIRE(cin == 64 || cin == 128 || cin == 256, "dt_head_mlp_f32: cin=%d (64, 128 or 256 supported)", cin);
-  if (g_head_cus <= 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
-      (void)hipGetLastError();
-      n = 256;
-    }
-    g_head_cus = n;
-  }
+  const int g_head_cus = device_cu_count();
   HeadArgs a;
   a.in = in_nhwc; a.wa = wa; a.wb = wb; a.tail = tail; a.out = out; a.out_exp = out_exp; a.pixels = pixels; a.cin = cin;
   const long tiles = (pixels + 31) / 32;

@@ -1,4 +1,7 @@
 // Library-level entry points: version, error text, device count, layout helpers, exp.
+#include <map>
+#include <mutex>
+
 #include "common.hpp"
 
 namespace dt {
@@ -14,6 +17,27 @@ int fail(const char* fmt, ...) {
   vsnprintf(err_buf(), 512, fmt, ap);
   va_end(ap);
   return 1;
+}
+
+int device_cu_count() {
+  static std::mutex mtx;
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  std::lock_guard<std::mutex> lock(mtx);
+  auto it = cus.find(dev);
+  if (it == cus.end()) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    it = cus.emplace(dev, n).first;
+  }
+  return it->second;
 }
 
 // [n, c, h*w] -> [n, h*w, c] through a 32x32 LDS tile (+1 pad: conflict-free column reads)

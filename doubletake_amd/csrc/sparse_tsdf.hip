@@ -346,7 +346,9 @@ __global__ __launch_bounds__(256) void sp_mc_generate_kernel(const SpGrid g, flo
   if (n == 0) return;
   // edge ids over the directory's voxel lattice, shifted to non-negative coordinates
   const long long L = (long long)g.nb * kSpRes, off = L >> 1;
-  const long long hash_mul = L + L * L + L * L * L;
+  // An edge joins two lattice points that differ by one step along one axis: id = (linear index of the lower endpoint) * 3
+  // + axis, unique and at most 3 L^3 (< 2^63 for any directory).  The dense kernel's v1 * hash_mul + v2 form would need
+  // ~L^6 and overflows int64 from L = 2048, i.e. 2 cm voxels at the default extent.
   for (int lz = 0; lz < kSpRes; ++lz) {
     int ci;
     float val[8], wts[8];
@@ -372,7 +374,8 @@ __global__ __launch_bounds__(256) void sp_mc_generate_kernel(const SpGrid g, flo
         verts[(size_t)idx * 3 + 2] = ((float)x1 * (1 - r) + (float)x2 * r) * g.voxel_size;
         if (vweights) vweights[idx] = wts[c1] * (1 - r) + wts[c2] * r;
         const long long a1 = (x1 + off) + (y1 + off) * L + (z1 + off) * L * L, a2 = (x2 + off) + (y2 + off) * L + (z2 + off) * L * L;
-        ids[idx] = a1 * hash_mul + a2;
+        const long long lo = a1 < a2 ? a1 : a2;
+        ids[idx] = lo * 3 + ((x1 != x2) ? 0 : ((y1 != y2) ? 1 : 2));
         if (t % 3 == 0) {
           const size_t f = (size_t)idx / 3;
           faces[f * 3 + 0] = idx;

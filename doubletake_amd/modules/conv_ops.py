@@ -56,6 +56,7 @@ def packed_weight(conv: nn.Conv2d, device, transposed=False):
     slot = "_dt_pack_t" if transposed else "_dt_pack"
     hit = getattr(conv, slot, None)
     if hit is not None and hit[0] == key:
+        _abi.wait_ready(hit[2], device)  # packed on another stream that may still be running
         return hit[1]
     co, ci, k, k2 = w.shape
     if (k != k2 or conv.groups != 1 or conv.dilation != (1, 1) or conv.padding != (k // 2, k // 2)
@@ -67,7 +68,7 @@ def packed_weight(conv: nn.Conv2d, device, transposed=False):
     packed = torch.empty(int(L.dt_conv_pack_floats(co, ci, k)), device=device, dtype=torch.float32)
     _abi.check(L.dt_conv_pack_f32(_abi.ptr(wd), _abi.ptr(packed), co, ci, k, _abi.current_stream(device)),
                "dt_conv_pack_f32")
-    setattr(conv, slot, (key, packed))
+    setattr(conv, slot, (key, packed, _abi.record_ready(device)))
     return packed
 
 
@@ -95,6 +96,7 @@ def packed_weight_wino(conv: nn.Conv2d, device):
     key = (w.data_ptr(), w._version, str(device))
     hit = getattr(conv, "_dt_pack_wino", None)
     if hit is not None and hit[0] == key:
+        _abi.wait_ready(hit[2], device)
         return hit[1]
     co, ci, k, k2 = w.shape
     if (k, k2) != (3, 3) or conv.stride != (1, 1) or conv.groups != 1 or conv.dilation != (1, 1) or conv.padding != (1, 1):
@@ -104,7 +106,7 @@ def packed_weight_wino(conv: nn.Conv2d, device):
     packed = torch.empty(int(L.dt_conv_wino_pack_floats(co, ci)), device=device, dtype=torch.float32)
     _abi.check(L.dt_conv_wino_pack_f32(_abi.ptr(wd), _abi.ptr(packed), co, ci, _abi.current_stream(device)),
                "dt_conv_wino_pack_f32")
-    conv._dt_pack_wino = (key, packed)
+    conv._dt_pack_wino = (key, packed, _abi.record_ready(device))
     return packed
 
 
@@ -125,9 +127,10 @@ def _dev_param(conv, name, device):
     cache = conv.__dict__.setdefault("_dt_small", {})
     hit = cache.get(name)
     if hit is not None and hit[0] == key:
+        _abi.wait_ready(hit[2], device)
         return hit[1]
-    val = p.detach().to(device=device, dtype=torch.float32).contiguous()
-    cache[name] = (key, val)
+    val = p.detach().to(device=device, dtype=torch.float32).contiguous()  # (a device-side cast/copy when p is on a GPU)
+    cache[name] = (key, val, _abi.record_ready(device))
     return val
 
 
@@ -221,8 +224,11 @@ PAIR_LAUNCH = _os.environ.get("DT_CONV_PAIR", "1") != "0"
 
 def conv2d_pair(srcs, conv_a: nn.Conv2d, act_a, conv_b: nn.Conv2d, act_b):
     """Two convolutions of the same (virtually concatenated) sources in one launch (dt_conv2d_pair_f32): the 3x3 ``conv_a``
-    and the shortcut ``conv_b`` (1x1 stride 1, or 3x3 stride 2) of a BasicBlock.  Returns (out_a, out_b), equal bit for bit
-    to two conv2d calls.  Shapes the paired kernel cannot take go through two conv2d calls."""
+    and the shortcut ``conv_b`` (1x1 stride 1, or 3x3 stride 2) of a BasicBlock.  Returns (out_a, out_b): the same products
+    as two conv2d calls, possibly in a different fp32 summation order (the pair plans its K splits jointly and may pick
+    another split width than a lone launch would: differences of a few 1e-6 on O(1) maps, see
+    tests/test_networks_gpu.py::test_paired_conv_launch_equals_two_launches).  Shapes the paired kernel cannot take go
+    through two conv2d calls."""
     co_a, co_b = conv_a.out_channels, conv_b.out_channels
     ka, sa, kb, sb = conv_a.kernel_size[0], conv_a.stride[0], conv_b.kernel_size[0], conv_b.stride[0]
     ok = (PAIR_LAUNCH and ka == 3 and sa == sb and co_a % 32 == 0 and co_b % 32 == 0 and all(t.shape[1] % 8 == 0 for t, _ in srcs)
@@ -279,8 +285,11 @@ def _head_pack(head: nn.Sequential, dev):
     if hit is None or hit[0] != key:
         arrs = [p.detach().float().cpu().numpy() for p in params]
         pk = mlp_pack.pack_head_mlp(*arrs)
-        hit = (key, {k: torch.from_numpy(v).to(dev) for k, v in pk.items()})
+        # (blocking host-to-device copies: complete on return, but the token keeps every cache uniform)
+        hit = (key, {k: torch.from_numpy(v).to(dev) for k, v in pk.items()}, _abi.record_ready(dev))
         head.__dict__["_dt_head_pack"] = hit
+    else:
+        _abi.wait_ready(hit[2], dev)
     return hit[1]
 
 

@@ -290,6 +290,7 @@ class FeatureVolumeManager(CostVolumeManager):
         key = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in params)
         hit = self._pack_cache.get("key")
         if hit == key:
+            _abi.wait_ready(self._pack_cache["ready"], device)
             return self._pack_cache["val"]
         arrs = [a.float().cpu().numpy() for a in self._mlp_arrays(self.mlp)]
         val = {}
@@ -305,7 +306,7 @@ class FeatureVolumeManager(CostVolumeManager):
         if self._has_hint:
             h = [a.float().cpu().numpy() for a in self._mlp_arrays(self.hint_mlp)]
             val["hint"] = torch.from_numpy(mlp_pack.pack_hint_mlp(*h)).to(device)
-        self._pack_cache = {"key": key, "val": val}
+        self._pack_cache = {"key": key, "val": val, "ready": _abi.record_ready(device)}
         return val
 
     # -- forward -------------------------------------------------------------------------------

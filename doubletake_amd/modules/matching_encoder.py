@@ -131,13 +131,16 @@ def stem_conv(image, conv: nn.Conv2d, bn: nn.BatchNorm2d):
         raise NotImplementedError("the fused stem is the ResNet conv1: Conv2d(3, 64, 7, stride 2, padding 3)")
     dev = image.device
     folded = _fold_bn(conv, bn, dev)
-    hit = folded.__dict__.get("_dt_stem_pack")
-    if hit is None:
+    ent = folded.__dict__.get("_dt_stem_pack")
+    if ent is None:
         packed = torch.empty(int(L.dt_stem_pack_floats()), device=dev, dtype=torch.float32)
         wd = folded.weight.detach().contiguous()
         _abi.check(L.dt_stem_pack_f32(_abi.ptr(wd), _abi.ptr(packed), _abi.current_stream(dev)), "dt_stem_pack_f32")
-        hit = packed
-        folded.__dict__["_dt_stem_pack"] = hit
+        ent = (packed, _abi.record_ready(dev))
+        folded.__dict__["_dt_stem_pack"] = ent
+    else:
+        _abi.wait_ready(ent[1], dev)  # packed on another stream that may still be running
+    hit = ent[0]
     img = image.float().contiguous()
     ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = ops.empty_nhwc(n, 64, ho, wo, dev)

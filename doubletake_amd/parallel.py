@@ -222,6 +222,13 @@ def unpack_tsdf(buf: torch.Tensor):
                 tsdf_values=body[:n].view(torch.float16).reshape(X, Y, Z), tsdf_weights=body[n:].view(torch.float16).reshape(X, Y, Z))
 
 
+def _collective_device():
+    """Device collectives of the default process group move: the current GPU under nccl (= RCCL), else the CPU."""
+    if _collective_ready() and "nccl" in str(dist.get_backend()):
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def gather_variable(payload: torch.Tensor, world: int, dst: int = 0, rank: int = 0):
     """Variable-size gather as two all_gathers: element counts first, then the payloads padded to the largest.
     ``payload`` is 1-D (may be empty).  Returns the list of ``world`` payloads on ``dst``, None elsewhere.
@@ -264,7 +271,9 @@ def run_scene_sharded(frame_counts, run_scene_fn, world: int, rank: int, on_scen
                 t = fuser.tsdf_fuser_pred.tsdf
                 payload = pack_tsdf(t.tsdf_values, t.tsdf_weights, t.origin_f32, t.voxel_size, scene)
         if payload is None:
-            payload = torch.empty(0, dtype=torch.uint8, device=device if device is not None else "cpu")
+            # a rank without a scan in this round still takes part in the collective, on the device the backend moves
+            # (RCCL: this rank's GPU; a CPU tensor here would error or hang the nccl all_gather -- ADVICE r2)
+            payload = torch.empty(0, dtype=torch.uint8, device=device if device is not None else _collective_device())
         got = gather_variable(payload, world, dst=0, rank=rank)
         if rank == 0 and on_scene_done is not None:
             done = [unpack_tsdf(g) for g in got if g.numel()]
