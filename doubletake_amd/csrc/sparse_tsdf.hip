@@ -46,6 +46,32 @@ struct SpCam {
   float c[3];    // camera centre in world
 };
 
+// Camera of one frame as it reaches the kernels: the two row-major 4x4 matrices, either by value (host pointers at the
+// C ABI) or as device pointers (dt_sparse_integrate_frames_f32: no host read of the cameras, hence no sync).  The derived
+// quantities are computed on the device in both cases, so the two entry points run the same arithmetic.
+struct SpCamSrc {
+  float K[16], T[16];
+  const float* K_dev;  // non-null: read K / T from device memory instead
+  const float* T_dev;
+};
+
+__host__ __device__ inline void fill_cam(SpCam& c, const float* K44, const float* T44) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      c.K[i * 3 + j] = K44[i * 4 + j];
+      c.R[i * 3 + j] = T44[i * 4 + j];
+      c.Rinv[i * 3 + j] = T44[j * 4 + i];  // rigid transform: inverse rotation = transpose
+    }
+  for (int i = 0; i < 3; ++i) c.t[i] = T44[i * 4 + 3];
+  for (int i = 0; i < 3; ++i) c.c[i] = -(c.Rinv[i * 3 + 0] * c.t[0] + c.Rinv[i * 3 + 1] * c.t[1] + c.Rinv[i * 3 + 2] * c.t[2]);
+}
+
+__device__ __forceinline__ SpCam sp_load_cam(const SpCamSrc& src) {
+  SpCam c;
+  fill_cam(c, src.K_dev ? src.K_dev : src.K, src.T_dev ? src.T_dev : src.T);
+  return c;
+}
+
 __device__ __forceinline__ long sp_dir_index(const SpGrid& g, int bx, int by, int bz) {
   const int h = g.nb >> 1;
   const int ix = bx + h, iy = by + h, iz = bz + h;
@@ -56,8 +82,9 @@ __device__ __forceinline__ long sp_dir_index(const SpGrid& g, int bx, int by, in
 // Open3D DepthTouch (VoxelBlockGridImpl.h, restated): pixels on a stride-4 lattice with 0 < d < depth_max; the ray
 // through pixel index (x, y) (no half-pixel offset) is sampled at 4 points from max(d - trunc, 0) to
 // min(d + trunc, depth_max); the block containing each point is activated.
-__global__ __launch_bounds__(256) void sp_touch_kernel(const SpGrid g, const SpCam cam, const float* __restrict__ depth, int H,
+__global__ __launch_bounds__(256) void sp_touch_kernel(const SpGrid g, const SpCamSrc cam_src, const float* __restrict__ depth, int H,
                                                       int W, float depth_max, float trunc) {
+  const SpCam cam = sp_load_cam(cam_src);
   const int stride = 4;
   const int cols = W / stride, rows = H / stride;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,8 +167,9 @@ __global__ __launch_bounds__(1024) void sp_allocate_kernel(const SpGrid g) {
 // (Open3D's voxel_coordinates are voxel corners, no half-voxel offset); pixel = round(u / w) (half away from zero);
 // tsdf = min(d - z, trunc) / trunc for d > 0, d < max_depth, d - z >= -trunc (x1.5 extended); confidence =
 // clip(1 - (d - 0.5) / (max_depth - 0.5), 0.25, 1)^2; w_new = confidence * 2.5 / 100; running mean; weight clipped to 1.
-__global__ __launch_bounds__(256) void sp_integrate_kernel(const SpGrid g, const SpCam cam, const float* __restrict__ depth,
+__global__ __launch_bounds__(256) void sp_integrate_kernel(const SpGrid g, const SpCamSrc cam_src, const float* __restrict__ depth,
                                                           int H, int W, float max_depth, float trunc, float min_sdf) {
+  const SpCam cam = sp_load_cam(cam_src);
   const int count = g.count[0];
   for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
     const int kx = g.keys[slot * 3 + 0], ky = g.keys[slot * 3 + 1], kz = g.keys[slot * 3 + 2];
@@ -405,15 +433,16 @@ static int fill_grid(SpGrid& g, int* dir, unsigned char* touch, int nb, float vo
   return 0;
 }
 
-static void fill_cam(SpCam& c, const float* K44, const float* T44) {
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      c.K[i * 3 + j] = K44[i * 4 + j];
-      c.R[i * 3 + j] = T44[i * 4 + j];
-      c.Rinv[i * 3 + j] = T44[j * 4 + i];  // rigid transform: inverse rotation = transpose
-    }
-  for (int i = 0; i < 3; ++i) c.t[i] = T44[i * 4 + 3];
-  for (int i = 0; i < 3; ++i) c.c[i] = -(c.Rinv[i * 3 + 0] * c.t[0] + c.Rinv[i * 3 + 1] * c.t[1] + c.Rinv[i * 3 + 2] * c.t[2]);
+static int integrate_one(const SpGrid& g, const SpCamSrc& cam, const float* depth_hw, int img_h, int img_w, float max_depth,
+                         float trunc_voxels, int extended_neg_truncation, hipStream_t st) {
+  const float trunc = trunc_voxels * g.voxel_size;
+  const int n = (img_h / 4) * (img_w / 4);
+  hipLaunchKernelGGL(sp_touch_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, cam, depth_hw, img_h, img_w, max_depth, trunc);
+  hipLaunchKernelGGL(sp_allocate_kernel, dim3(1), dim3(1024), 0, st, g);
+  const int wgs = g.cap < 2048 ? g.cap : 2048;
+  hipLaunchKernelGGL(sp_integrate_kernel, dim3(wgs), dim3(256), 0, st, g, cam, depth_hw, img_h, img_w, max_depth, trunc,
+                     extended_neg_truncation ? -1.5f * trunc : -trunc);
+  return 0;
 }
 
 }  // namespace dt
@@ -432,17 +461,33 @@ int dt_sparse_integrate_f32(int* dir, unsigned char* touch, int nb, float voxel_
   if (int rc = fill_grid(g, dir, touch, nb, voxel_size, keys, tsdf, weight, count2, capacity, "dt_sparse_integrate_f32")) return rc;
   DT_REQUIRE(depth_hw && K44_host && cam_T_world44_host, "dt_sparse_integrate_f32: null pointer");
   DT_REQUIRE(img_h >= 4 && img_w >= 4 && max_depth > 0.f && trunc_voxels > 0.f, "dt_sparse_integrate_f32: bad extents");
-  SpCam cam;
-  fill_cam(cam, K44_host, cam_T_world44_host);
-  const float trunc = trunc_voxels * voxel_size;
-  hipStream_t st = to_stream(s);
-  const int n = (img_h / 4) * (img_w / 4);
-  hipLaunchKernelGGL(sp_touch_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, cam, depth_hw, img_h, img_w, max_depth, trunc);
-  hipLaunchKernelGGL(sp_allocate_kernel, dim3(1), dim3(1024), 0, st, g);
-  const int wgs = capacity < 2048 ? capacity : 2048;
-  hipLaunchKernelGGL(sp_integrate_kernel, dim3(wgs), dim3(256), 0, st, g, cam, depth_hw, img_h, img_w, max_depth, trunc,
-                     extended_neg_truncation ? -1.5f * trunc : -trunc);
+  SpCamSrc cam;
+  for (int i = 0; i < 16; ++i) {
+    cam.K[i] = K44_host[i];
+    cam.T[i] = cam_T_world44_host[i];
+  }
+  cam.K_dev = cam.T_dev = nullptr;
+  integrate_one(g, cam, depth_hw, img_h, img_w, max_depth, trunc_voxels, extended_neg_truncation, to_stream(s));
   return check_launch("dt_sparse_integrate_f32");
+}
+
+int dt_sparse_integrate_frames_f32(int* dir, unsigned char* touch, int nb, float voxel_size, int* keys, float* tsdf, float* weight,
+                                   int* count2, int capacity, const float* depth_nhw, int num_frames, int img_h, int img_w,
+                                   const float* K_n44_dev, const float* cam_T_world_n44_dev, float max_depth, float trunc_voxels,
+                                   int extended_neg_truncation, dt_stream_t s) {
+  SpGrid g;
+  if (int rc = fill_grid(g, dir, touch, nb, voxel_size, keys, tsdf, weight, count2, capacity, "dt_sparse_integrate_frames_f32")) return rc;
+  DT_REQUIRE(depth_nhw && K_n44_dev && cam_T_world_n44_dev, "dt_sparse_integrate_frames_f32: null pointer");
+  DT_REQUIRE(num_frames > 0 && img_h >= 4 && img_w >= 4 && max_depth > 0.f && trunc_voxels > 0.f,
+             "dt_sparse_integrate_frames_f32: bad extents");
+  SpCamSrc cam = {};
+  for (int f = 0; f < num_frames; ++f) {  // frame order = integration order (the running mean is order dependent)
+    cam.K_dev = K_n44_dev + (size_t)f * 16;
+    cam.T_dev = cam_T_world_n44_dev + (size_t)f * 16;
+    integrate_one(g, cam, depth_nhw + (size_t)f * img_h * img_w, img_h, img_w, max_depth, trunc_voxels, extended_neg_truncation,
+                  to_stream(s));
+  }
+  return check_launch("dt_sparse_integrate_frames_f32");
 }
 
 int dt_sparse_sample_f32(int* dir, unsigned char* touch, int nb, float voxel_size, int* keys, float* tsdf, float* weight,

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from ..modules import conv_ops as ops
-from ..modules.cost_volume import FeatureMeshHintVolumeManager
+from ..modules.cost_volume import CostVolumeManager, FeatureMeshHintVolumeManager, FeatureVolumeManager
 from ..modules.networks import CVEncoder, DepthDecoderPP, ResnetMatchingEncoder
 from ..modules.networks_fast import SkipDecoderRegression
 
@@ -59,24 +59,38 @@ class MatchingFeatureCache:
         self._store.clear()
 
 
-class DepthModelCVHint(nn.Module):
-    #: option fields the reference constructor reads (experiment_modules/doubletake_model.py:84-204)
+#: feature_volume_type -> manager class.  DepthModel (SimpleRecon, sr_depth_model.py:186-194) accepts the first two,
+#: DepthModelCVHint (doubletake_model.py:172-177) the third.
+VOLUME_CLASSES = {
+    "simple_cost_volume": CostVolumeManager,
+    "mlp_feature_volume": FeatureVolumeManager,
+    "mlp_mesh_hint_feature_volume": FeatureMeshHintVolumeManager,
+}
+
+
+class _HotPathDepthModel(nn.Module):
+    """What DepthModel (experiment_modules/sr_depth_model.py) and DepthModelCVHint (doubletake_model.py) share: the
+    modules the HIP kernels replace under the reference's attribute names, compute_matching_feats, and the forward
+    from encoder features on.  Subclasses state which ``feature_volume_type`` values they accept and the default."""
+
+    #: option fields the reference constructors read (doubletake_model.py:84-204, sr_depth_model.py:100-230)
     _OPT_FIELDS = ("image_height", "image_width", "image_encoder_name", "depth_decoder_name", "matching_num_depth_bins",
                    "matching_scale", "matching_feature_dims", "model_num_views", "min_matching_depth", "max_matching_depth",
-                   "matching_encoder_type")
+                   "matching_encoder_type", "feature_volume_type")
+    _VOLUME_TYPES = ()
+    _DEFAULT_VOLUME_TYPE = None
 
     def __init__(self, image_height=384, image_width=512, image_encoder_name="resnet18d", depth_decoder_name="skip",
                  matching_num_depth_bins=64, matching_scale=1, matching_feature_dims=16, model_num_views=8,
-                 min_matching_depth=0.25, max_matching_depth=5.0, matching_encoder_type="resnet"):
-        """Keyword form, or the reference's ``DepthModelCVHint(opts)`` with an options object / namespace that
-        carries the fields of ``_OPT_FIELDS`` (missing ones keep the reference defaults of options.py)."""
+                 min_matching_depth=0.25, max_matching_depth=5.0, matching_encoder_type="resnet", feature_volume_type=None):
+        """Keyword form, or the reference's ``Model(opts)`` with an options object / namespace that carries the fields
+        of ``_OPT_FIELDS`` (missing ones keep the reference defaults of options.py)."""
         super().__init__()
         if not isinstance(image_height, int) and hasattr(image_height, "image_height"):
             opts = image_height
-            for bad, want in (("cv_encoder_type", "multi_scale_encoder"), ("feature_volume_type", "mlp_mesh_hint_feature_volume"),
-                              ("loss_type", "log_l1")):
+            for bad, want in (("cv_encoder_type", "multi_scale_encoder"), ("loss_type", "log_l1")):
                 if getattr(opts, bad, want) != want:
-                    raise NotImplementedError(f"{bad}={getattr(opts, bad)!r}: only {want!r} (the DoubleTake configuration) is built")
+                    raise ValueError(f"Unrecognized option {getattr(opts, bad)!r} for {bad} (the reference builds only {want!r})")
             self.run_opts = opts
             image_height = opts.image_height
             image_width = getattr(opts, "image_width", image_width)
@@ -89,6 +103,14 @@ class DepthModelCVHint(nn.Module):
             min_matching_depth = getattr(opts, "min_matching_depth", min_matching_depth)
             max_matching_depth = getattr(opts, "max_matching_depth", max_matching_depth)
             matching_encoder_type = getattr(opts, "matching_encoder_type", matching_encoder_type)
+            feature_volume_type = getattr(opts, "feature_volume_type", feature_volume_type)
+        if feature_volume_type is None:
+            feature_volume_type = self._DEFAULT_VOLUME_TYPE
+        if feature_volume_type not in self._VOLUME_TYPES:
+            # same refusal as the reference (sr_depth_model.py:190-194, doubletake_model.py:174-177)
+            raise ValueError(f"Unrecognized option {feature_volume_type} for feature volume type! "
+                             f"{type(self).__name__} builds {', '.join(self._VOLUME_TYPES)}")
+        self.feature_volume_type = feature_volume_type
         key = "efficientnet" if "efficientnet" in image_encoder_name else "resnet18d"
         self.num_ch_enc = list(ENCODER_WIDTHS[key])
         self.matching_scale = matching_scale
@@ -103,7 +125,7 @@ class DepthModelCVHint(nn.Module):
             self.depth_decoder = SkipDecoderRegression(dec_in)
         else:
             raise ValueError("Unrecognized option for depth decoder name!")
-        self.cost_volume = FeatureMeshHintVolumeManager(
+        self.cost_volume = VOLUME_CLASSES[feature_volume_type](
             matching_height=image_height // (2 ** (matching_scale + 1)),
             matching_width=image_width // (2 ** (matching_scale + 1)),
             num_depth_bins=matching_num_depth_bins, matching_dim_size=matching_feature_dims,
@@ -168,7 +190,7 @@ class DepthModelCVHint(nn.Module):
 
     @torch.no_grad()
     def forward_from_features(self, cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
-                              cur_cam_T_src_cam, src_K, cur_invK, cv_depth_hint_dict, return_mask=False):
+                              cur_cam_T_src_cam, src_K, cur_invK, cv_depth_hint_dict=None, return_mask=False):
         """cur_feats: list of 5 image-prior maps (strides 2..32); matching feats at stride 4.
         Returns the reference's output dict (doubletake_model.py:410-423)."""
         dev = matching_cur_feats.device
@@ -178,10 +200,12 @@ class DepthModelCVHint(nn.Module):
             self._max_depth = torch.tensor(self.max_matching_depth, device=dev, dtype=torch.float32).view(1, 1, 1, 1)
             self._depth_range_key = key
         min_depth, max_depth = self._min_depth, self._max_depth
-        cost_volume, lowest_cost, _, overall_mask = self.cost_volume(
-            cur_feats=matching_cur_feats, src_feats=matching_src_feats, src_extrinsics=src_cam_T_cur_cam,
-            src_poses=cur_cam_T_src_cam, src_Ks=src_K, cur_invK=cur_invK, min_depth=min_depth, max_depth=max_depth,
-            return_mask=return_mask, cv_depth_hint_dict=cv_depth_hint_dict)
+        kw = dict(cur_feats=matching_cur_feats, src_feats=matching_src_feats, src_extrinsics=src_cam_T_cur_cam,
+                  src_poses=cur_cam_T_src_cam, src_Ks=src_K, cur_invK=cur_invK, min_depth=min_depth, max_depth=max_depth,
+                  return_mask=return_mask)
+        if isinstance(self.cost_volume, FeatureMeshHintVolumeManager):  # the other managers take no hints
+            kw["cv_depth_hint_dict"] = cv_depth_hint_dict
+        cost_volume, lowest_cost, _, overall_mask = self.cost_volume(**kw)
         cv_feats = self.cost_volume_net(cost_volume, cur_feats[self.matching_scale:])
         feats = list(cur_feats[: self.matching_scale]) + cv_feats
         if isinstance(self.depth_decoder, SkipDecoderRegression):
@@ -214,3 +238,20 @@ class DepthModelCVHint(nn.Module):
                                                    unbatched_matching_encoder_forward)  # (ids: opt-in, see above)
         return self.forward_from_features(cur_feats, m_cur, m_src, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K,
                                           cur_invK, cur_data, return_mask=return_mask)
+
+
+class DepthModelCVHint(_HotPathDepthModel):
+    """DoubleTake (experiment_modules/doubletake_model.py): the mesh-hint feature volume; ``cur_data`` carries the hint
+    maps (depth_hint_b1hw, sampled_weights_b1hw, depth_hint_mask_b1hw)."""
+
+    _VOLUME_TYPES = ("mlp_mesh_hint_feature_volume",)
+    _DEFAULT_VOLUME_TYPE = "mlp_mesh_hint_feature_volume"
+
+
+class DepthModel(_HotPathDepthModel):
+    """SimpleRecon (experiment_modules/sr_depth_model.py:186-204), ``model_type == "depth_model"``: the dot-product
+    ``simple_cost_volume`` or the metadata ``mlp_feature_volume`` (the options.py default), no hints.  Same modules,
+    state-dict keys and forward contract (:283-420) as the reference class."""
+
+    _VOLUME_TYPES = ("simple_cost_volume", "mlp_feature_volume")
+    _DEFAULT_VOLUME_TYPE = "mlp_feature_volume"

@@ -5,6 +5,11 @@
 ``two_pass_fns``          -- reference test_offline_two_pass.py:26-131 (first pass, empty hints, hint TSDF at
                             0.04 m / 3 m) and :292-500 (second pass, hints from the finished first-pass mesh) as the
                             two step functions ``parallel.run_two_pass`` shards over GPUs.
+``revisit_fns``           -- reference test_revisit.py:104-260: the hint mesh comes from a first pass over a PREVIOUS scan
+                            of the same place (:122-156, compute_hint_mesh), the second pass runs over the new scan with
+                            hints rendered from that mesh through the rigid transform between the two scans' world frames.
+``FrameTimer``            -- the per-frame ``model_time`` / ``hint_time`` the reference drivers record with CUDA events
+                            (test_incremental.py:107-111,274-288; test_revisit.py:233-256) and average into the score sheet.
 
 The dataset / dataloader, metric averaging, visualisation and file output of those scripts are out of scope
 (SURVEY.md section 2); a batch here is the pair of dicts ``(cur_data, src_data)`` the reference dataloaders yield,
@@ -16,7 +21,63 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+from . import _abi
 from .utils.rendering_utils import MeshDepthRenderer, empty_hint, prepare_mesh_hint, prepare_mesh_hint_fused
+
+
+class FrameTimer:
+    """``model_time`` / ``hint_time`` per frame in milliseconds, from HIP events on the current stream.
+
+    The reference brackets the hint preparation and the model call with CUDA events and calls
+    ``torch.cuda.synchronize()`` after each to read them (test_incremental.py:107-111,205,256-258,274-288), then feeds
+    ``elapsed / batch_size`` per element into its ResultsAverager.  Here the events are kept and read once, in
+    ``summary()`` -- the loop itself stays free of host synchronisation (``sync_each_frame=True`` restores the
+    reference's behaviour for like-for-like timing).  ``write_scores`` stores the averages through the reference's score
+    sheet format (utils/formats.py:write_scores_json = utils/metrics_utils.py ResultsAverager.output_json)."""
+
+    def __init__(self, sync_each_frame=False):
+        self.sync_each_frame = sync_each_frame
+        self._open = {}
+        self._spans = {"hint_time": [], "model_time": []}
+
+    def start(self, what):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._open[what] = ev
+
+    def stop(self, what, batch_size=1):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._spans[what].append((self._open.pop(what), ev, int(batch_size)))
+        if self.sync_each_frame:
+            torch.cuda.synchronize()
+
+    def skip(self, what, batch_size=1):
+        """A frame without this phase (the first frame of the incremental mode has no hint to render): 0 ms."""
+        self._spans[what].append((None, None, int(batch_size)))
+
+    def per_frame(self):
+        """{"hint_time": [...], "model_time": [...]}: one entry per batch ELEMENT (elapsed / batch size, as the reference)."""
+        torch.cuda.synchronize()
+        out = {}
+        for what, spans in self._spans.items():
+            vals = []
+            for a, b, n in spans:
+                ms = 0.0 if a is None else a.elapsed_time(b)
+                vals += [ms / n] * n
+            out[what] = vals
+        return out
+
+    def summary(self):
+        pf = self.per_frame()
+        return {k: (sum(v) / len(v) if v else 0.0) for k, v in pf.items()}
+
+    def write_scores(self, filepath, exp_name, metrics_name="frame metrics", extra=None):
+        from .utils import formats
+
+        scores = dict(extra or {})
+        scores.update(self.summary())
+        return formats.write_scores_json(filepath, exp_name, metrics_name, scores)
 
 
 def _depth_for_fusion(outputs, size, mask_pred_depth=False, per_view_mask=True):
@@ -38,14 +99,15 @@ def _depth_for_fusion(outputs, size, mask_pred_depth=False, per_view_mask=True):
 
 @torch.no_grad()
 def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fused_hint=True, mask_pred_depth=False,
-                         on_frame=None):
+                         on_frame=None, timer: FrameTimer | None = None):
     """One scan of the incremental (online) mode; batch size 1 (reference test_incremental.py:25).
 
     batches: iterable of (cur_data, src_data); cur_data carries K_s0_b44 / invK_s0_b44 / cam_T_world_b44 /
     world_T_cam_b44 / K_full_depth_b44 (+ whatever model_fn reads).  The hint entries (depth_hint_b1hw,
     depth_hint_mask_b1hw, depth_hint_mask_b_b1hw, sampled_weights_b1hw) are written into cur_data here.
     fused_hint: marching-cubes soup -> raster -> one back-project/sample/threshold kernel (4 launches) instead of the
-    reference-shaped sequence over a merged mesh.  Returns the number of frames fused."""
+    reference-shaped sequence over a merged mesh.  timer: a FrameTimer that receives hint_time / model_time per frame
+    (test_incremental.py:205,256-258,274-288).  Returns the number of frames fused."""
     H2, W2 = render_hw
     renderer = None if fused_hint else MeshDepthRenderer(H2, W2)
     n = 0
@@ -53,14 +115,24 @@ def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fu
         if cur_data["cam_T_world_b44"].shape[0] != 1:
             raise ValueError("the incremental mode needs batch size 1 (frame t depends on the TSDF after frame t-1)")
         if i > 0:
+            if timer is not None:
+                timer.start("hint_time")
             if fused_hint:
                 prepare_mesh_hint_fused(fuser, cur_data, H2, W2)
             else:
                 prepare_mesh_hint(fuser, renderer, cur_data, H2, W2)
+            if timer is not None:
+                timer.stop("hint_time")
         else:
             ref = cur_data["cam_T_world_b44"]
             empty_hint(cur_data, torch.zeros(1, 1, H2, W2, device=ref.device, dtype=torch.float32))
+            if timer is not None:
+                timer.skip("hint_time")
+        if timer is not None:
+            timer.start("model_time")
         outputs = model_fn(cur_data, src_data)
+        if timer is not None:
+            timer.stop("model_time")
         depth = _depth_for_fusion(outputs, fuse_size, mask_pred_depth, per_view_mask=True)
         fuser.fuse_frames(depth, cur_data["K_full_depth_b44"], cur_data["cam_T_world_b44"], None)
         n += 1
@@ -69,18 +141,68 @@ def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fu
     return n
 
 
-def two_pass_fns(model_fn, load_batch, render_hw, fuse_size=None, mask_pred_depth=False, on_frame=None):
+@torch.no_grad()
+def hints_from_mesh(mesh, hint_fuser, renderer, cur_data, render_hw, hint_world_T_world_144=None):
+    """Second-pass hint maps of a keyframe batch (test_offline_two_pass.py:311-358, test_revisit.py:194-231): depth
+    rendered from the finished hint mesh, weights sampled from the hint TSDF per batch element, NO 0.025 cut (commented
+    out in the reference, two_pass :354-356), weights zeroed outside the render mask.  One raster launch + one fused
+    back-project / sample / mask launch (dt_hint_from_depth_f32 with the cut disabled) per batch element -- round 2 built
+    these maps from a dozen torch ops and a Python loop over elements.
+
+    hint_world_T_world_144: rigid transform taking this scan's world frame to the hint mesh's world frame
+    (test_revisit.py:112-114 ``first_scan_T_second_scan``); None when both live in the same frame (two-pass)."""
+    import ctypes as C
+
+    H2, W2 = render_hw
+    L = _abi.lib()
+    tsdf = hint_fuser.tsdf_fuser_pred.tsdf
+    dev = tsdf.device
+    b = cur_data["cam_T_world_b44"].shape[0]
+    pose = cur_data["world_T_cam_b44"].to(device=dev, dtype=torch.float32)
+    if hint_world_T_world_144 is not None:
+        pose = hint_world_T_world_144.to(device=dev, dtype=torch.float32) @ pose   # first_scan_world_T_cam, :202-205
+        cam_T_world = torch.inverse(pose)
+    else:
+        cam_T_world = cur_data["cam_T_world_b44"].to(device=dev, dtype=torch.float32)
+    pose = pose.contiguous()
+    K = cur_data["K_s0_b44"].clone()
+    K[:, 0] /= W2
+    K[:, 1] /= H2
+    depth, _ = renderer.render(mesh, cam_T_world.clone(), K)
+    invK = cur_data["invK_s0_b44"].to(device=dev, dtype=torch.float32).contiguous()
+    hint = torch.empty_like(depth)
+    mask_f = torch.empty_like(depth)
+    mask_b = torch.empty(b, 1, H2, W2, device=dev, dtype=torch.bool)
+    weights = torch.empty_like(depth)
+    o = (C.c_float * 3)(*[float(v) for v in tsdf.origin.float().tolist()])
+    X, Y, Z = tsdf.tsdf_weights.shape
+    stream = _abi.current_stream(dev)
+    for j in range(b):  # the reference samples element by element too (:334-341)
+        _abi.check(L.dt_hint_from_depth_f32(_abi.ptr(depth[j]), _abi.ptr(tsdf.tsdf_weights), o, float(tsdf.voxel_size), X, Y, Z,
+                                            _abi.ptr(invK[j]), _abi.ptr(pose[j]), float("-inf"), H2, W2, _abi.ptr(hint[j]),
+                                            _abi.ptr(mask_f[j]), _abi.ptr(mask_b[j]), _abi.ptr(weights[j]), stream),
+                   "dt_hint_from_depth_f32")
+    cur_data["depth_hint_b1hw"] = hint
+    cur_data["depth_hint_mask_b_b1hw"] = mask_b
+    cur_data["depth_hint_mask_b1hw"] = mask_f
+    cur_data["sampled_weights_b1hw"] = weights
+    return depth
+
+
+def two_pass_fns(model_fn, load_batch, render_hw, fuse_size=None, mask_pred_depth=False, on_frame=None,
+                 load_first_pass_batch=None, hint_world_T_world_144=None, timer: FrameTimer | None = None):
     """(first_pass_fn, between_passes, second_pass_fn) for ``parallel.run_two_pass``.
 
     ``load_batch(i) -> (cur_data, src_data)`` fetches keyframe batch i onto this rank's GPU (only called for the
-    rank's own batches).  Second-pass hints follow test_offline_two_pass.py:311-358: depth rendered from the
-    first-pass mesh, weights sampled from the first-pass TSDF per batch element, NO 0.025 cut (commented out in the
-    reference, :354-356), weights zeroed outside the render mask."""
+    rank's own batches).  Second-pass hints: ``hints_from_mesh``.  ``load_first_pass_batch`` / ``hint_world_T_world_144``
+    serve ``revisit_fns`` (first pass over another scan; hints through a rigid transform).  timer: second-pass
+    hint_time / model_time per frame (test_offline_two_pass.py:313,360-362,371-377)."""
     H2, W2 = render_hw
+    load_first = load_first_pass_batch if load_first_pass_batch is not None else load_batch
 
     @torch.no_grad()
     def first(i):
-        cur_data, src_data = load_batch(i)
+        cur_data, src_data = load_first(i)
         b = cur_data["cam_T_world_b44"].shape[0]
         empty_hint(cur_data, torch.zeros(b, 1, H2, W2, device=cur_data["cam_T_world_b44"].device, dtype=torch.float32))
         out = model_fn(cur_data, src_data)
@@ -94,32 +216,38 @@ def two_pass_fns(model_fn, load_batch, render_hw, fuse_size=None, mask_pred_dept
     @torch.no_grad()
     def second(i, state):
         cur_data, src_data = load_batch(i)
-        dev = cur_data["cam_T_world_b44"].device
         b = cur_data["cam_T_world_b44"].shape[0]
-        K = cur_data["K_s0_b44"].clone()
-        K[:, 0] /= W2
-        K[:, 1] /= H2
-        depth, _ = state["renderer"].render(state["mesh"], cur_data["cam_T_world_b44"].clone(), K)
-        hint = depth.clone()
-        hint[hint == -1] = float("nan")
-        mask_b = ~torch.isnan(hint)
-        ys, xs = torch.meshgrid(torch.arange(H2, device=dev), torch.arange(W2, device=dev), indexing="ij")
-        pix = torch.stack([xs.flatten() + 0.5, ys.flatten() + 0.5, torch.ones(H2 * W2, device=dev)], 0)
-        weights = []
-        for j in range(b):  # :334-341 samples element by element
-            cam = (cur_data["invK_s0_b44"][j, :3, :3].float() @ pix) * depth[j].reshape(1, -1)
-            world = (cur_data["world_T_cam_b44"][j].float() @ torch.cat([cam, torch.ones_like(cam[:1])], 0))[:3].t().contiguous()
-            weights.append(state["hint_fuser"].sample_tsdf(world, what_to_sample="weights"))
-        weights = torch.stack(weights, 0).view(b, 1, H2, W2).clone()
-        weights[~mask_b] = 0.0
-        cur_data["depth_hint_b1hw"] = hint
-        cur_data["depth_hint_mask_b_b1hw"] = mask_b
-        cur_data["depth_hint_mask_b1hw"] = mask_b.float()
-        cur_data["sampled_weights_b1hw"] = weights
+        if timer is not None:
+            timer.start("hint_time")
+        hints_from_mesh(state["mesh"], state["hint_fuser"], state["renderer"], cur_data, (H2, W2), hint_world_T_world_144)
+        if timer is not None:
+            timer.stop("hint_time", b)
+            timer.start("model_time")
         out = model_fn(cur_data, src_data)
+        if timer is not None:
+            timer.stop("model_time", b)
         if on_frame is not None:
             on_frame(i, cur_data, out)
         return _depth_for_fusion(out, fuse_size, mask_pred_depth, per_view_mask=False), cur_data["K_full_depth_b44"], \
             cur_data["cam_T_world_b44"]
 
     return first, between, second
+
+
+def revisit_fns(model_fn, load_first_scan_batch, load_batch, first_scan_T_second_scan_144, render_hw, fuse_size=None,
+                mask_pred_depth=False, on_frame=None, timer: FrameTimer | None = None):
+    """The revisit flow of reference test_revisit.py:104-260 as the step functions of ``parallel.run_two_pass``
+    (``num_first_batches=`` gives the first scan's batch count):
+
+      first(i)          one keyframe batch of the PREVIOUS scan with empty hints (compute_hint_mesh, :122-156 -> the
+                        hint TSDF at 0.04 m / 3 m that ``run_two_pass`` fuses, like the two-pass first pass)
+      between(fuser)    marching cubes of that TSDF, once
+      second(i, state)  one keyframe batch of the NEW scan: hints rendered from the previous scan's mesh with the camera
+                        ``inverse(first_scan_T_second_scan @ world_T_cam)`` and weights sampled at
+                        ``first_scan_T_second_scan @ world_T_cam @ cam_points`` (:194-231), then the model; the returned
+                        depth / K / cam_T_world fuse into the NEW scan's volume in its own world frame (:262-316).
+
+    ``first_scan_T_second_scan_144``: [1,4,4], the inverse of the rescan transform the 3RScan metadata lists (:112-114)."""
+    return two_pass_fns(model_fn, load_batch, render_hw, fuse_size=fuse_size, mask_pred_depth=mask_pred_depth,
+                        on_frame=on_frame, load_first_pass_batch=load_first_scan_batch,
+                        hint_world_T_world_144=first_scan_T_second_scan_144, timer=timer)

@@ -160,7 +160,7 @@ def run_sharded_pass(num_batches, batch_size_of, step_fn, shard_fuser: KeyframeS
 
 
 def run_two_pass(num_batches, batch_size_of, first_pass_fn, second_pass_fn, hint_shard_fuser, final_shard_fuser,
-                 between_passes=None):
+                 between_passes=None, num_first_batches=None, first_batch_size_of=None):
     """Offline two-pass over one scan (reference test_offline_two_pass.py:26-131 then :292-500).
 
     Pass 1 (``first_pass_fn``: model with empty hints) fills every rank's replica of the 0.04 m / 3 m hint TSDF
@@ -168,8 +168,13 @@ def run_two_pass(num_batches, batch_size_of, first_pass_fn, second_pass_fn, hint
     (``get_mesh_pytorch3d``, reference :129) is extracted locally on every rank -- no collective --
     in ``between_passes(hint_fuser)`` whose result is handed to ``second_pass_fn(batch_index, hint_state)``.
     Pass 2 renders hints from that mesh, samples the hint TSDF's weights, runs the model and fuses into the final
-    volume (``final_shard_fuser``, may be None when fusion is off)."""
-    n1 = run_sharded_pass(num_batches, batch_size_of, first_pass_fn, hint_shard_fuser)
+    volume (``final_shard_fuser``, may be None when fusion is off).
+
+    Revisit flow (reference test_revisit.py:104-260, ``loops.revisit_fns``): the first pass runs over ANOTHER scan --
+    ``num_first_batches`` / ``first_batch_size_of`` describe that scan's keyframe batches (default: the same schedule)."""
+    nb1 = num_batches if num_first_batches is None else num_first_batches
+    n1 = run_sharded_pass(nb1, first_batch_size_of if first_batch_size_of is not None else batch_size_of, first_pass_fn,
+                          hint_shard_fuser)
     state = between_passes(hint_shard_fuser.fuser) if between_passes is not None else None
     if final_shard_fuser is None:
         mine = shard_keyframes(num_batches, hint_shard_fuser.world, hint_shard_fuser.rank)

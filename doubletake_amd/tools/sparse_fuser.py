@@ -97,11 +97,14 @@ class CustomOpen3dFuser(DepthFuser):
         g = self.volume
         dev = g.device
         depth = depths_b1hw.to(device=dev, dtype=torch.float32).contiguous()
-        K = K_b44.detach().float().cpu().contiguous().numpy()
-        T = cam_T_world_b44.detach().float().cpu().contiguous().numpy()
-        h, w = depth.shape[-2:]
+        # cameras stay on the device (dt_sparse_integrate_frames_f32 reads them there): no .cpu() -- i.e. no device
+        # synchronisation -- per call, one entry-point call per CHECK_EVERY-aligned run of frames
+        K = K_b44.detach().to(device=dev, dtype=torch.float32).contiguous()
+        T = cam_T_world_b44.detach().to(device=dev, dtype=torch.float32).contiguous()
+        n, (h, w) = depth.shape[0], depth.shape[-2:]
         stream = _abi.current_stream(dev)
-        for i in range(depth.shape[0]):
+        i = 0
+        while i < n:
             # the pool is sized generously (288 GB of HBM); the allocation counter is read back every CHECK_EVERY frames
             # (and at every mesh extraction): the pool doubles once it is half full, and a block that did not fit is never
             # silent -- num_blocks() raises
@@ -109,12 +112,14 @@ class CustomOpen3dFuser(DepthFuser):
                 used = g.num_blocks()
                 if used * 2 > g.capacity:
                     g.grow(2 * g.capacity)
-            k = K[i].astype(np.float32).ravel()
-            t = T[i].astype(np.float32).ravel()
-            _abi.check(L.dt_sparse_integrate_f32(*g.args(), _abi.ptr(depth[i, 0]), h, w, k.ctypes.data_as(C.POINTER(C.c_float)),
-                                                 t.ctypes.data_as(C.POINTER(C.c_float)), float(self.max_fusion_depth), 3.0,
-                                                 int(bool(self.extended_neg_truncation)), stream), "dt_sparse_integrate_f32")
-            self.frames_fused += 1
+            run = min(n - i, self.CHECK_EVERY - (self.frames_fused + 1) % self.CHECK_EVERY) if self.CHECK_EVERY > 1 else 1
+            run = max(1, run)
+            _abi.check(L.dt_sparse_integrate_frames_f32(*g.args(), _abi.ptr(depth[i:i + run]), run, h, w, _abi.ptr(K[i:i + run]),
+                                                        _abi.ptr(T[i:i + run]), float(self.max_fusion_depth), 3.0,
+                                                        int(bool(self.extended_neg_truncation)), stream),
+                       "dt_sparse_integrate_frames_f32")
+            self.frames_fused += run
+            i += run
 
     @torch.no_grad()
     def _extract(self, weight_threshold=None, trim_tsdf_using_confience=False):

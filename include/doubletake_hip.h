@@ -370,6 +370,13 @@ int dt_sparse_integrate_f32(int* dir, unsigned char* touch, int nb, float voxel_
                             int* count2, int capacity, const float* depth_hw, int img_h, int img_w, const float* K44_host,
                             const float* cam_T_world44_host, float max_depth, float trunc_voxels, int extended_neg_truncation,
                             dt_stream_t s);
+/* The same for num_frames depth maps [n,h,w] with their cameras in DEVICE memory ([n,16] floats each, row-major 4x4),
+ * integrated in order: no host read of the cameras, hence no device synchronisation in the fusion loop
+ * (tools/fusers_helper.py:288-336 loops over the batch on the host with .cpu() cameras). */
+int dt_sparse_integrate_frames_f32(int* dir, unsigned char* touch, int nb, float voxel_size, int* keys, float* tsdf, float* weight,
+                                   int* count2, int capacity, const float* depth_nhw, int num_frames, int img_h, int img_w,
+                                   const float* K_n44_dev, const float* cam_T_world_n44_dev, float max_depth,
+                                   float trunc_voxels, int extended_neg_truncation, dt_stream_t s);
 /* trilinear sample of the tsdf (what=0) or weight (what=1) field at world points; unallocated corners read 0 */
 int dt_sparse_sample_f32(int* dir, unsigned char* touch, int nb, float voxel_size, int* keys, float* tsdf, float* weight,
                          int* count2, int capacity, const float* points_N3, float* out_N, int64_t n, int what, dt_stream_t s);

@@ -145,3 +145,160 @@ def test_offline_two_pass_on_one_gpu():
     a, c = hint_fuser.tsdf_fuser_pred.tsdf, check.tsdf_fuser_pred.tsdf
     assert torch.equal(a.tsdf_values.view(torch.int16), c.tsdf_values.view(torch.int16))
     assert (final_fuser.tsdf_fuser_pred.tsdf.tsdf_weights > 0).sum().item() > 5000
+
+
+@pytest.mark.parametrize("volume_type,golden_key,tol", [("simple_cost_volume", "dot_volume", 5e-4), ("mlp_feature_volume", "mlp_volume", 5e-5)])
+@pytest.mark.parametrize("case", ["k2_land", "k7_land"])
+def test_depth_model_simple_and_mlp_volume_types(case, volume_type, golden_key, tol):
+    """DepthModel (SimpleRecon, sr_depth_model.py:186-204) reaches the dot-product and the no-hint MLP managers through the
+    model class: its volume equals the reference golden of that manager, and forward_from_features equals the chain of its
+    parts and the numpy oracle of the conv stacks on that golden volume (depth within 1e-3)."""
+    import gpu_util as gu
+    from conftest import load_golden
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModel
+    from oracle import networks_ref as nref
+
+    dev = gu.dev()
+    g = load_golden(f"volume_{case}.npz")
+    b, k, h, w, D, seed, empty, behind = [int(v) for v in g["meta"]]
+    inp = syn.volume_inputs(b, k, h, w, 16, seed, empty_hint=bool(empty), behind_view=bool(behind))
+    t = gu.to_dev(inp)
+    model = DepthModel(4 * h, 4 * w, depth_decoder_name="skip", matching_num_depth_bins=D, model_num_views=k + 1,
+                       min_matching_depth=float(inp["min_depth"].reshape(-1)[0]), max_matching_depth=float(inp["max_depth"].reshape(-1)[0]),
+                       feature_volume_type=volume_type, matching_encoder_type=None)
+    gu.set_formula_weights(model, 21)
+    if volume_type == "mlp_feature_volume":
+        gu.load_formula_mlp(model.cost_volume.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 11 + seed)
+    model = model.to(dev).eval()
+    pyr = syn.prior_pyramid(b, [64, 64, 128, 256, 512], 2 * h, 2 * w, 4)
+    pyr_t = [torch.from_numpy(p).to(dev) for p in pyr]
+    out = model.forward_from_features(pyr_t, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"], t["src_Ks"],
+                                      t["cur_invK"], return_mask=True)
+    vol, low, _, mask = model.cost_volume(**gu.volume_call_args(t), return_mask=True)
+    torch.cuda.synchronize()
+    assert np.abs(vol.cpu().numpy() - g[golden_key]).max() < tol
+    assert torch.equal(out["lowest_cost_bhw"], low)
+    if volume_type == "simple_cost_volume":
+        assert out["overall_mask_bhw"] is None and mask is None  # cost_volume.py: the dot-product manager returns no mask
+    else:
+        np.testing.assert_array_equal(out["overall_mask_bhw"].cpu().numpy(), g["mlp_mask_slow"])
+    # conv stacks on the REFERENCE volume through the numpy oracle
+    sd = {n: v.detach().cpu().numpy() for n, v in model.state_dict().items()}
+    sub = lambda pre: {n[len(pre):]: v for n, v in sd.items() if n.startswith(pre)}
+    cv = nref.cv_encoder(g[golden_key], pyr[1:], sub("cost_volume_net."))
+    ref = nref.skip_decoder_regression([pyr[0]] + cv, sub("depth_decoder."))
+    for i in range(4):
+        got = out[f"depth_pred_s{i}_b1hw"].cpu().numpy()
+        want = np.exp(ref[f"log_depth_pred_s{i}_b1hw"])
+        assert np.abs(got - want).max() < 1e-3, (i, np.abs(got - want).max())
+
+
+def _second_pass_hints_torch(state, cur_data, H2, W2, first_T_second=None):
+    """The reference's op sequence (test_offline_two_pass.py:311-358 / test_revisit.py:194-231) with torch ops -- the form
+    loops.py used in round 2; kept here as the checker of the fused hints_from_mesh."""
+    dev = cur_data["cam_T_world_b44"].device
+    b = cur_data["cam_T_world_b44"].shape[0]
+    K = cur_data["K_s0_b44"].clone()
+    K[:, 0] /= W2
+    K[:, 1] /= H2
+    pose = cur_data["world_T_cam_b44"].float()
+    if first_T_second is not None:
+        pose = first_T_second.to(dev).float() @ pose
+    depth, _ = state["renderer"].render(state["mesh"], torch.inverse(pose).clone(), K)
+    hint = depth.clone()
+    hint[hint == -1] = float("nan")
+    mask_b = ~torch.isnan(hint)
+    ys, xs = torch.meshgrid(torch.arange(H2, device=dev), torch.arange(W2, device=dev), indexing="ij")
+    pix = torch.stack([xs.flatten() + 0.5, ys.flatten() + 0.5, torch.ones(H2 * W2, device=dev)], 0)
+    weights = []
+    for j in range(b):
+        cam = (cur_data["invK_s0_b44"][j, :3, :3].float() @ pix) * depth[j].reshape(1, -1)
+        world = (pose[j] @ torch.cat([cam, torch.ones_like(cam[:1])], 0))[:3].t().contiguous()
+        weights.append(state["hint_fuser"].sample_tsdf(world, what_to_sample="weights"))
+    weights = torch.stack(weights, 0).view(b, 1, H2, W2).clone()
+    weights[~mask_b] = 0.0
+    return hint, mask_b, weights
+
+
+def test_revisit_flow_and_fused_second_pass_hints_on_one_gpu(tmp_path):
+    """loops.revisit_fns (reference test_revisit.py:104-260) through parallel.run_two_pass with world size 1: the previous
+    scan is the same room in a shifted world frame, so (i) the hint TSDF holds the previous scan's frames, (ii) the hints
+    the new scan sees through first_scan_T_second_scan equal the reference's op sequence evaluated with torch ops (fused
+    kernel, cut disabled: weights within 2e-6, identical masks), with and without the rigid transform, (iii) the per-frame
+    hint_time / model_time land in the reference's score sheet format."""
+    import gpu_util as gu
+    from doubletake_amd import loops, parallel
+    from doubletake_amd.tools.fusers_helper import OurFuser
+    from doubletake_amd.utils import formats
+
+    dev = gu.dev()
+    H, W, k, D, b, nb, nb1 = 128, 160, 2, 16, 2, 3, 2
+    H2, W2 = H // 2, W // 2
+    model = _model(H, W, k, D, dev)
+    cams = _cams(b * nb, H2, W2)
+    surface, _, _ = syn.tsdf_frames(1, H2, W2, seed=3, bounds=BD)
+    base = torch.from_numpy(surface[0:1] * np.float32(0.55)).to(dev)
+    shift = torch.tensor([[1, 0, 0, 0.08], [0, 1, 0, -0.04], [0, 0, 1, 0.02], [0, 0, 0, 1.0]], device=dev)[None]  # first_T_second
+    seen = {"cover": []}
+
+    def model_fn(cur_data, src_data):
+        out = model("test", cur_data, src_data, return_mask=True)
+        out["depth_pred_s0_b1hw"] = base + 0.02 * torch.tanh(out["depth_pred_s0_b1hw"] - 1.0)
+        seen["cover"].append(float(cur_data["depth_hint_mask_b1hw"].mean()))
+        return out
+
+    load = lambda i: _batch(i, b, k, H, W, dev, cams)
+
+    def load_first(i):  # previous scan: the same cameras expressed in ITS world frame (world_first = shift @ world_new)
+        cur, src = load(i)
+        cur["world_T_cam_b44"] = (shift @ cur["world_T_cam_b44"]).contiguous()
+        cur["cam_T_world_b44"] = torch.inverse(cur["world_T_cam_b44"]).contiguous()
+        src["world_T_cam_b44"] = (shift[:, None] @ src["world_T_cam_b44"]).contiguous()
+        src["cam_T_world_b44"] = torch.inverse(src["world_T_cam_b44"]).contiguous()
+        return cur, src
+
+    checks = []
+
+    def on_frame(i, cur_data, out):
+        want = _second_pass_hints_torch(state_box["s"], load(i)[0], H2, W2, shift)
+        checks.append((cur_data["depth_hint_b1hw"].clone(), cur_data["depth_hint_mask_b_b1hw"].clone(),
+                       cur_data["sampled_weights_b1hw"].clone(), want))
+
+    timer = loops.FrameTimer()
+    first, between, second = loops.revisit_fns(model_fn, load_first, load, shift, (H2, W2), fuse_size=(H, W), on_frame=on_frame,
+                                               timer=timer)
+    state_box = {}
+
+    def between_rec(f):
+        state_box["s"] = between(f)
+        return state_box["s"]
+
+    bd_first = dict(xmin=-2.2, xmax=2.2, ymin=-2.2, ymax=2.2, zmin=-0.2, zmax=2.6)
+    hint_fuser = OurFuser(None, 0.04, 3.0, bounds=bd_first)
+    final_fuser = OurFuser(None, 0.04, 3.0, bounds=BD)
+    sf_hint = parallel.KeyframeShardFuser(dev, 1, 0, (H, W), fuser=hint_fuser)
+    sf_final = parallel.KeyframeShardFuser(dev, 1, 0, (H, W), fuser=final_fuser)
+    n1, n2 = parallel.run_two_pass(nb, lambda i: b, first, second, sf_hint, sf_final, between_passes=between_rec,
+                                   num_first_batches=nb1)
+    torch.cuda.synchronize()
+    assert (n1, n2) == (b * nb1, b * nb)
+    assert seen["cover"][:nb1] == [0.0] * nb1 and min(seen["cover"][nb1:]) > 0.2
+    assert len(checks) == nb
+    for hint, mask_b, weights, (w_hint, w_mask, w_weights) in checks:
+        assert torch.equal(mask_b, w_mask) and mask_b.dtype == torch.bool
+        assert torch.equal(torch.isnan(hint), torch.isnan(w_hint))
+        assert torch.equal(hint[mask_b], w_hint[w_mask])
+        assert (weights - w_weights).abs().max().item() < 2e-6
+        assert float(weights[~mask_b].abs().max()) == 0.0 and float(weights.max()) > 0.5  # no 0.025 cut, zero outside the render
+    # without the transform (= the two-pass second pass) the same equality holds
+    cur, _ = load(0)
+    st = between(hint_fuser)
+    loops.hints_from_mesh(st["mesh"], hint_fuser, st["renderer"], cur, (H2, W2))
+    w_hint, w_mask, w_weights = _second_pass_hints_torch(st, load(0)[0], H2, W2)
+    assert torch.equal(cur["depth_hint_mask_b_b1hw"], w_mask) and (cur["sampled_weights_b1hw"] - w_weights).abs().max().item() < 2e-6
+    # timing sheet (test_revisit.py:233-256 -> ResultsAverager JSON)
+    pf = timer.per_frame()
+    assert len(pf["hint_time"]) == len(pf["model_time"]) == b * nb and min(pf["model_time"]) > 0 and min(pf["hint_time"]) > 0
+    doc = timer.write_scores(str(tmp_path / "scores.json"), "revisit", extra={"abs_diff": 0.1})
+    back = formats.read_scores_json(str(tmp_path / "scores.json"))
+    assert list(back["scores"]) == ["abs_diff", "hint_time", "model_time"] and back["scores"]["model_time"] == doc["scores"]["model_time"]

@@ -87,7 +87,11 @@ def test_incremental_loop_cfg4_size():
         fused.append(up[0, 0].cpu().numpy())
 
     fuser = OurFuser(None, 0.04, 3.0, bounds=BD)
-    n = loops.run_incremental_scan(model_fn, fuser, frames, (H2, W2), fuse_size=(H, W), on_frame=on_frame)
+    timer = loops.FrameTimer()
+    n = loops.run_incremental_scan(model_fn, fuser, frames, (H2, W2), fuse_size=(H, W), on_frame=on_frame, timer=timer)
+    times = timer.per_frame()  # test_incremental.py:274-288: model_time / hint_time per frame (ms)
+    assert len(times["model_time"]) == len(times["hint_time"]) == NFRAMES
+    assert times["hint_time"][0] == 0.0 and min(times["hint_time"][1:]) > 0.0 and min(times["model_time"]) > 0.0
     torch.cuda.synchronize()
     assert n == NFRAMES
     # one observation stays below the 0.025 weight cut (tools/tsdf.py:546-549); from the third frame on the hint covers the view

@@ -149,3 +149,33 @@ def test_get_fuser_builds_the_sparse_fuser():
     assert isinstance(f, CustomOpen3dFuser) and f.volume.num_blocks() == 0
     mesh, v, fc = f.get_mesh_pytorch3d()
     assert v.shape == (1, 3)
+
+
+def test_device_camera_entry_point_equals_host_camera_entry_point():
+    """dt_sparse_integrate_frames_f32 (cameras read on the device: no .cpu() sync in fuse_frames) against the per-frame
+    dt_sparse_integrate_f32 with host cameras: same slots, tiles bit for bit; 40 frames cross the CHECK_EVERY read-back."""
+    import ctypes as C
+
+    import gpu_util as gu
+    from doubletake_amd import _abi
+    from doubletake_amd.tools.sparse_fuser import CustomOpen3dFuser
+
+    n = 40
+    depth, K, T = _frames(n)
+    d, k, t = (torch.from_numpy(a).to(gu.dev()) for a in (depth, K, T))
+    a = CustomOpen3dFuser(fusion_resolution=0.04, max_fusion_depth=3.0)
+    a.fuse_frames(d[:3], k[:3], t[:3], None)      # ragged calls: 3 + 37 frames
+    a.fuse_frames(d[3:], k[3:], t[3:], None)
+    b = CustomOpen3dFuser(fusion_resolution=0.04, max_fusion_depth=3.0)
+    L = _abi.lib()
+    fp = lambda m: np.ascontiguousarray(m, dtype=np.float32).ravel().ctypes.data_as(C.POINTER(C.c_float))
+    for i in range(n):
+        Ki, Ti = np.ascontiguousarray(K[i], np.float32), np.ascontiguousarray(T[i], np.float32)
+        _abi.check(L.dt_sparse_integrate_f32(*b.volume.args(), _abi.ptr(d[i, 0]), depth.shape[-2], depth.shape[-1], fp(Ki), fp(Ti),
+                                             3.0, 3.0, 0, _abi.current_stream(gu.dev())), "dt_sparse_integrate_f32")
+    torch.cuda.synchronize()
+    na, nb_ = a.volume.num_blocks(), b.volume.num_blocks()
+    assert na == nb_ > 50 and a.frames_fused == n
+    assert torch.equal(a.volume.block_keys(), b.volume.block_keys())
+    assert torch.equal(a.volume.tsdf[: na * 4096], b.volume.tsdf[: na * 4096])
+    assert torch.equal(a.volume.weight[: na * 4096], b.volume.weight[: na * 4096])
