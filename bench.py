@@ -35,8 +35,30 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-CFG = dict(image_h=480, image_w=640, num_src=7, planes=64, batch=1)
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+# --config: the BASELINE.json shapes (the default is the one the metric is quoted on, configs[1]).  The names are those of
+# the full-size parity cases (tests/test_model_fullsize_gpu.py), which check the same model instances against checksums
+# captured from the reference.
+CONFIGS = {
+    "cfg2_small": dict(image_h=480, image_w=640, num_src=7, planes=64, batch=1, decoder="skip", encoder="resnet18d",
+                       what="DoubleTake-small, 640x480, 7 source views, 64 planes, batch=1 per GPU (BASELINE.json configs[1])"),
+    "cfg2_full": dict(image_h=480, image_w=640, num_src=7, planes=64, batch=1, decoder="unet_pp", encoder="efficientnet",
+                      what="DoubleTake full model (DepthDecoderPP), 640x480, 7 source views, 64 planes, batch=1 per GPU"),
+    "cfg3_full_b8": dict(image_h=384, image_w=512, num_src=7, planes=64, batch=8, decoder="unet_pp", encoder="efficientnet",
+                         what="DoubleTake full model, 512x384, 7 source views, 64 planes, batch=8 per GPU (BASELINE.json configs[2])"),
+    "cfg3_small_b8": dict(image_h=384, image_w=512, num_src=7, planes=64, batch=8, decoder="skip", encoder="resnet18d",
+                          what="DoubleTake-small, 512x384, 7 source views, 64 planes, batch=8 per GPU"),
+    "cfg4_small": dict(image_h=384, image_w=512, num_src=7, planes=64, batch=1, decoder="skip", encoder="resnet18d",
+                       what="DoubleTake-small at the incremental mode's frame shape, 512x384, batch=1 (BASELINE.json configs[3]; "
+                            "the online loop itself -- hint render + model + fuse per frame -- is timed by scripts/time_incremental.py)"),
+    "cfg5_full_d96": dict(image_h=512, image_w=384, num_src=7, planes=96, batch=2, decoder="unet_pp", encoder="efficientnet",
+                          what="DoubleTake full model, portrait 384x512, 96 planes, batch=2 per GPU (BASELINE.json configs[4] shape)"),
+    "cfg5_small_d96": dict(image_h=512, image_w=384, num_src=7, planes=96, batch=2, decoder="skip", encoder="resnet18d",
+                           what="DoubleTake-small, portrait 384x512, 96 planes, batch=2 per GPU"),
+}
+ENC_WIDTHS = {"resnet18d": [64, 64, 128, 256, 512], "efficientnet": [24, 48, 64, 160, 256]}
+CFG = dict(CONFIGS["cfg2_small"])
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)" = "Peak FP32 (vector)"
+PEAK_LDS_TBPS = 256 * 256 * 2.4e9 / 1e12  # 256 CUs x 256 B/clk (ds_read_b128, same guide, LDS table) x 2.4 GHz = 157 TB/s
 
 
 def volume_flops(b, k, h, w, D):
@@ -52,7 +74,7 @@ def build_inputs(device, seed):
     h, w = CFG["image_h"] // 4, CFG["image_w"] // 4
     b, k = CFG["batch"], CFG["num_src"]
     inp = syn.volume_inputs(b, k, h, w, 16, seed)
-    widths = [64, 64, 128, 256, 512]
+    widths = ENC_WIDTHS[CFG["encoder"]]
     pyr = syn.prior_pyramid(b, widths, 2 * h, 2 * w, seed + 50)
     t = {n: torch.from_numpy(v).to(device) for n, v in inp.items()}
     pyr_t = [torch.from_numpy(p).to(device).contiguous(memory_format=torch.channels_last) for p in pyr]
@@ -64,7 +86,7 @@ def build_model(device):
     from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
     from doubletake_amd.utils import synthetic as syn
 
-    m = DepthModelCVHint(CFG["image_h"], CFG["image_w"], image_encoder_name="resnet18d", depth_decoder_name="skip",
+    m = DepthModelCVHint(CFG["image_h"], CFG["image_w"], image_encoder_name=CFG["encoder"], depth_decoder_name=CFG["decoder"],
                          matching_num_depth_bins=CFG["planes"], model_num_views=CFG["num_src"] + 1)
     shapes = [tuple(p.shape) for _, p in m.named_parameters()]
     arrs = syn.formula_params(shapes, 2024)
@@ -206,8 +228,15 @@ def dot_volume_roofline(device, t, launches=30):
         ms = float(np.mean([evs[i].elapsed_time(evs[i + 1]) for i in range(0, len(evs), 2)]))
         algo = 4.0 * b * h * w * (c * (k + 1) + D)
         taps = 4.0 * b * h * w * D * k * 4 * c
-        return {"avg_launch_ms": ms, "achieved": algo / (ms * 1e-3) / 1e9, "frac": algo / (ms * 1e-3) / 1e9 / 8000.0,
-                "algorithmic_bytes_per_launch": algo, "bilinear_tap_bytes_per_launch": taps, "tap_GBps": taps / (ms * 1e-3) / 1e9}
+        # what really bounds this kernel (SURVEY section 7 asks for both next to the HBM fraction):
+        #   VALU: per (pixel, plane, view) sample 4 taps x 16 channels of blend FMAs + 16 dot FMAs (= 160 flop) + ~26 flop of
+        #         projection and tap weights, against the fp32 vector peak;
+        #   LDS : the tap bytes, against 256 B/clk/CU conflict-free ds_read_b128 bandwidth
+        valu_flops = 186.0 * b * h * w * D * k
+        t_s = ms * 1e-3
+        return {"avg_launch_ms": ms, "achieved": algo / t_s / 1e9, "frac": algo / t_s / 1e9 / 8000.0,
+                "algorithmic_bytes_per_launch": algo, "bilinear_tap_bytes_per_launch": taps, "tap_GBps": taps / t_s / 1e9,
+                "valu_frac": valu_flops / t_s / 1e12 / PEAK_F32_MFMA_TFLOPS, "lds_frac": taps / t_s / 1e12 / PEAK_LDS_TBPS}
 
     h, w = CFG["image_h"] // 4, CFG["image_w"] // 4
     main = measure(t, CFG["batch"], h, w, "lds")
@@ -221,8 +250,12 @@ def dot_volume_roofline(device, t, launches=30):
         "algorithmic_bytes_per_launch": main["algorithmic_bytes_per_launch"],
         "bilinear_tap_bytes_per_launch": main["bilinear_tap_bytes_per_launch"], "tap_GBps": main["tap_GBps"],
         "avg_launch_ms": main["avg_launch_ms"],
+        "valu_frac": main["valu_frac"], "lds_frac": main["lds_frac"],
+        "bounds": "valu_frac = 186 flop per (pixel, plane, view) sample / time / 157.3 TF fp32 vector peak; lds_frac = bilinear tap "
+                  f"bytes / time / {PEAK_LDS_TBPS:.0f} TB/s (256 CUs x 256 B/clk x 2.4 GHz); frac = compulsory HBM bytes / time / 8 TB/s",
         "direct_global_taps": {kk: direct[kk] for kk in ("avg_launch_ms", "achieved", "frac", "tap_GBps")},
-        "batch8_512x384": {kk: b8[kk] for kk in ("avg_launch_ms", "achieved", "frac", "algorithmic_bytes_per_launch", "tap_GBps")},
+        "batch8_512x384": {kk: b8[kk] for kk in ("avg_launch_ms", "achieved", "frac", "algorithmic_bytes_per_launch", "tap_GBps",
+                                                  "valu_frac", "lds_frac")},
     }
 
 
@@ -255,6 +288,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2_small",
+                    help="BASELINE.json shape to run (default: configs[1], the one the metric is quoted on); the other shapes "
+                         "print the same one-line JSON without the cpu_baseline / dot-kernel side legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", default="8,all", help="thread counts of the cpu_baseline leg ('all' = physical cores)")
     ap.add_argument("--cpu-batched", action="store_true", help="also time the batched (Fast-manager) CPU volume once")
@@ -272,6 +308,9 @@ def main():
                     help="with --gpus 1: still create the RCCL process group and run the per-step all_gather "
                          "(checks the N>1 code path on a single GPU)")
     args = ap.parse_args()
+    CFG.clear()
+    CFG.update(CONFIGS[args.config])
+    default_cfg = args.config == "cfg2_small"
 
     import torch
     import torch.distributed as dist
@@ -327,11 +366,12 @@ def main():
         T_pool16 = torch.from_numpy(Tp).to(device).half()
 
     events = []
+    L = _abi.lib()
 
     def hook(tag):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream(device))
-        events.append((tag, ev))
+        events.append((tag, ev, int(L.dt_kernel_launch_count())))
 
     def model_step():
         return model.forward_from_features(pyr_t, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"],
@@ -402,6 +442,8 @@ def main():
             gs[2].replay()
         else:
             out = model_step()
+            if timed:
+                hook("model_end")  # mlp_end .. model_end = lowest-cost/mask + CVEncoder + decoder + heads
         if fuser is not None:
             b = CFG["batch"]
             j = [((frame_idx * world + rank) * b + i) % POOL for i in range(b)]  # global keyframe index -> camera
@@ -415,6 +457,10 @@ def main():
                 fuse_done["ev"].record(cur)
         return out
 
+    # one eager step on the default stream first: weight packs, per-stream scratch and allocator pools are created
+    # before the steps fan out over the streams (the pack caches also order themselves across streams: _abi.wait_ready)
+    step_on_current(0)
+    torch.cuda.synchronize(device)
     if streams is not None:
         for st in streams:
             st.wait_stream(torch.cuda.current_stream(device))
@@ -456,15 +502,40 @@ def main():
         cvmod.FeatureVolumeManager._event_hook = None
         ev1 = events[n_main:]
         del events[n_main:]
-        b1 = [e for tag, e in ev1 if tag == "mlp_begin"]
-        e1 = [e for tag, e in ev1 if tag == "mlp_end"]
+        b1 = [e for tag, e, _ in ev1 if tag == "mlp_begin"]
+        e1 = [e for tag, e, _ in ev1 if tag == "mlp_end"]
+        m1 = [e for tag, e, _ in ev1 if tag == "model_end"]
         single = {"value": args.steps * CFG["batch"] / el1, "ms_per_step": el1 / args.steps * 1e3,
                   "dominant_kernel_avg_launch_ms": float(np.mean([b.elapsed_time(e) for b, e in zip(b1, e1)]))}
+        if m1:
+            single["conv_stack_avg_ms"] = float(np.mean([b.elapsed_time(e) for b, e in zip(e1, m1)]))
 
     # dominant kernel: average launch duration from the HIP events recorded on its stream
-    begins = [e for tag, e in events if tag == "mlp_begin"]
-    ends = [e for tag, e in events if tag == "mlp_end"]
+    begins = [e for tag, e, _ in events if tag == "mlp_begin"]
+    ends = [e for tag, e, _ in events if tag == "mlp_end"]
+    mends = [e for tag, e, _ in events if tag == "model_end"]
     kern_ms = float(np.mean([b.elapsed_time(e) for b, e in zip(begins, ends)])) if begins else float("nan")
+    conv_ms = float(np.mean([b.elapsed_time(e) for b, e in zip(ends, mends)])) if mends else float("nan")
+    # launches of one step: library kernels between the hooks of the last timed step (host-side counter)
+    n_conv_launches = n_model_launches = None
+    if mends:
+        cb = [c for tag, _, c in events if tag == "mlp_begin"][-1]
+        ce = [c for tag, _, c in events if tag == "mlp_end"][-1]
+        cm = [c for tag, _, c in events if tag == "model_end"][-1]
+        n_conv_launches = cm - ce
+    # direct-convolution-equivalent FLOPs of the conv stack + heads of one step (one extra, untimed step with the op-level
+    # accounting switched on)
+    conv_flops = None
+    if graphs is None:
+        from doubletake_amd.modules import conv_ops as _ops
+
+        _ops.ACCOUNT = {"flops": 0.0, "calls": 0}
+        c0 = int(L.dt_kernel_launch_count())
+        model_step()
+        n_model_launches = int(L.dt_kernel_launch_count()) - c0
+        torch.cuda.synchronize(device)
+        conv_flops = _ops.ACCOUNT["flops"]
+        _ops.ACCOUNT = None
 
     if rank == 0:
         h, w = CFG["image_h"] // 4, CFG["image_w"] // 4
@@ -475,7 +546,7 @@ def main():
         # the last scripts/collect_pmc.sh pass -- and only while the kernel source it was measured on is the one built now
         traffic, traffic_tag = None, None
         tf = os.path.join(REPO, "profiles", "roofline_traffic.json")
-        if os.path.isfile(tf):
+        if os.path.isfile(tf) and default_cfg and args.mlp_precision == "fp32":
             try:
                 import hashlib
 
@@ -487,7 +558,8 @@ def main():
             except Exception:
                 traffic = None
         result = {
-            "metric": "depth frames/sec (640x480, 7 src views, 64 planes)",
+            "metric": "depth frames/sec (640x480, 7 src views, 64 planes)" if default_cfg else
+                      f"depth frames/sec ({CFG['image_w']}x{CFG['image_h']}, {CFG['num_src']} src views, {CFG['planes']} planes, batch {CFG['batch']})",
             "value": frames / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -500,8 +572,9 @@ def main():
             "dtype": "f32" if args.mlp_precision == "fp32" else "f32 (opt-in: MLP products as split fp16 hi/lo pairs, f32 accumulate)",
             "data": "synthetic",
             "config": {
-                "workload": "DoubleTake-small hot path: mesh-hint cost volume + CVEncoder + SkipDecoderRegression, "
-                            "640x480, 7 source views, 64 planes, batch=1 per GPU (BASELINE.json configs[1])",
+                "workload": "hot path (mesh-hint cost volume + CVEncoder + "
+                            + ("SkipDecoderRegression" if CFG["decoder"] == "skip" else "DepthDecoderPP") + " + exp): " + CFG["what"],
+                "name": args.config,
                 "matching_resolution": [h, w],
                 "frames_per_step_per_gpu": CFG["batch"],
                 "streams": args.streams,
@@ -522,12 +595,28 @@ def main():
                 "avg_launch_ms": kern_ms,
             },
         }
+        if conv_flops is not None and conv_ms == conv_ms:
+            # the conv stack next to the dominant kernel: direct-convolution-equivalent FLOPs (the Winograd layers execute
+            # 2.25x fewer multiplies) over the HIP-event time from the end of the volume kernel to the end of the model
+            iso_ms = single.get("conv_stack_avg_ms") if single is not None else None
+            result["roofline_conv"] = {
+                "kernels": "cv_lowest_cost + cv_mask + conv_wino / conv_mfma / conv_pair (CVEncoder, decoder) + head_mlp",
+                "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
+                "direct_equivalent_flops_per_step": conv_flops,
+                "launches": n_conv_launches, "model_launches_per_step": n_model_launches,
+                "avg_ms": conv_ms, "achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
+                "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "avg_ms_single_stream": iso_ms,
+                "frac_single_stream": (conv_flops / (iso_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if iso_ms else None,
+            }
         if single is not None:
             single["frac_of_mfma_peak_isolated"] = flops / (single["dominant_kernel_avg_launch_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
             result["single_stream"] = single
-        if world == 1:
+        if world == 1 and default_cfg:
             result["roofline_warp_match_dot"] = dot_volume_roofline(device, t)
-        if world == 1 and not args.no_cpu_baseline:
+        if not default_cfg:
+            result["cpu_baseline"] = None  # the CPU leg is defined on the default workload
+        if world == 1 and default_cfg and not args.no_cpu_baseline:
             base, ref_depths = cpu_baseline(inp, pyr, model, args.cpu_threads, args.cpu_batched)
             # the CPU frame doubles as a full-size parity check of the whole path (checker only, outside the timed
             # region): north-star tolerance 1e-3 abs depth

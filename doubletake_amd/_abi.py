@@ -39,6 +39,7 @@ SIGNATURES = {
     "dt_version": (_I, []),
     "dt_last_error": (C.c_char_p, []),
     "dt_device_count": (_I, []),
+    "dt_kernel_launch_count": (_L, []),
     "dt_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dt_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dt_cv_params_floats": (_I, [_I, _I]),

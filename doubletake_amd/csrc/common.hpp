@@ -24,6 +24,15 @@ inline hipStream_t to_stream(dt_stream_t s) { return reinterpret_cast<hipStream_
 // compute units of HIP's CURRENT device (cached per device id: one process may drive several GPUs); 256 if unknown
 int device_cu_count();
 
+// Every kernel launch of the library goes through DT_LAUNCH so that dt_kernel_launch_count() can report how many
+// kernels a step needed (bench.py: launches of the conv stack; cheap: one relaxed atomic add per launch).
+void note_launch();
+#define DT_LAUNCH(...)                \
+  do {                                \
+    ::dt::note_launch();              \
+    hipLaunchKernelGGL(__VA_ARGS__);  \
+  } while (0)
+
 #define DT_REQUIRE(cond, ...)            \
   do {                                   \
     if (!(cond)) return dt::fail(__VA_ARGS__); \

@@ -1296,7 +1296,7 @@ static int attach_scratch(hipStream_t st, ConvArgs* a, long blocks_a, ConvArgs* 
 template <int KS, int ST>
 static void launch_split16(const ConvArgs& a, long blocks, hipStream_t st) {
   if constexpr (ST == 1)
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, ST, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
+    DT_LAUNCH((conv_mfma_kernel<KS, ST, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
 }
 
 }  // namespace dt
@@ -1314,7 +1314,7 @@ int dt_conv_pack_f32(const float* W, float* packed, int c_out, int c_in, int ksi
   DT_REQUIRE(ksize == 1 || ksize == 3, "dt_conv_pack_f32: ksize=%d", ksize);
   const size_t total = (size_t)c_out * c_in * ksize * ksize;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, to_stream(s), W, packed, c_out, c_in, ksize);
+  DT_LAUNCH(conv_pack_kernel, dim3(blocks), dim3(256), 0, to_stream(s), W, packed, c_out, c_in, ksize);
   return check_launch("dt_conv_pack_f32");
 }
 
@@ -1359,12 +1359,12 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
   do {                                                                                                             \
     DT_REQUIRE(!a.tr || split != 1, "dt_conv2d_f32: transposed tiling needs a K-split kernel (see dt_conv_transposed_tiling)"); \
     if (split == 1)                                                                                                \
-      hipLaunchKernelGGL((conv_mfma_wshare_kernel<KS_, ST_>),                                                      \
+      DT_LAUNCH((conv_mfma_wshare_kernel<KS_, ST_>),                                                      \
                          dim3((unsigned)((((long)a.n * a.tiles_y * a.tiles_x + 3) / 4) * a.co_blocks)), dim3(256), 0, st, a); \
     else if (split == 4)                                                                                           \
-      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);               \
+      DT_LAUNCH((conv_mfma_kernel<KS_, ST_, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);               \
     else                                                                                                           \
-      hipLaunchKernelGGL((conv_mfma_kernel<KS_, ST_, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);               \
+      DT_LAUNCH((conv_mfma_kernel<KS_, ST_, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);               \
   } while (0)
   if (d->ksize == 3 && d->stride == 1)
     DT_LAUNCH_CONV(3, 1);
@@ -1378,10 +1378,10 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
     if (waves < 1024 && a.groups >= 32 && blocks * 8 < 2048)
       launch_split16<1, 1>(a, blocks, st);
     else if (waves < 1024 && a.groups >= 16)
-      hipLaunchKernelGGL((conv_mfma_kernel<1, 1, 8>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+      DT_LAUNCH((conv_mfma_kernel<1, 1, 8>), dim3((unsigned)blocks), dim3(512), 0, st, a);
     else {
       DT_REQUIRE(!a.tr, "dt_conv2d_f32: transposed tiling needs a K-split kernel (see dt_conv_transposed_tiling)");
-      hipLaunchKernelGGL(conv1x1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+      DT_LAUNCH(conv1x1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
     }
   }
 #undef DT_LAUNCH_CONV
@@ -1413,7 +1413,7 @@ int dt_conv_wino_pack_f32(const float* W, float* packed, int c_out, int c_in, dt
   DT_REQUIRE(c_in > 0 && c_in % 8 == 0, "dt_conv_wino_pack_f32: c_in=%d must be a multiple of 8", c_in);
   const size_t total = (size_t)c_out * c_in * 16;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(conv_wino_pack_kernel, dim3(blocks), dim3(256), 0, to_stream(s), W, packed, c_out, c_in);
+  DT_LAUNCH(conv_wino_pack_kernel, dim3(blocks), dim3(256), 0, to_stream(s), W, packed, c_out, c_in);
   return check_launch("dt_conv_wino_pack_f32");
 }
 
@@ -1457,11 +1457,11 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
   const long grid = a.kplain + (blocks - a.kplain) * a.kparts;
   if (int rc = attach_scratch(to_stream(s), &a, blocks, nullptr, 0, 4096)) return rc;
   if (ksplit == 4)
-    hipLaunchKernelGGL(conv_wino_kernel<4>, dim3((unsigned)grid), dim3(1024), 0, to_stream(s), a);
+    DT_LAUNCH(conv_wino_kernel<4>, dim3((unsigned)grid), dim3(1024), 0, to_stream(s), a);
   else if (ksplit == 2)
-    hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)grid), dim3(512), 0, to_stream(s), a);
+    DT_LAUNCH(conv_wino_kernel<2>, dim3((unsigned)grid), dim3(512), 0, to_stream(s), a);
   else
-    hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)grid), dim3(256), 0, to_stream(s), a);
+    DT_LAUNCH(conv_wino_kernel<1>, dim3((unsigned)grid), dim3(256), 0, to_stream(s), a);
   return check_launch("dt_conv2d_wino_f32");
 }
 
@@ -1511,7 +1511,7 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
   using M324 = MfmaBody<3, 2, 4>;
 #define DT_PAIR(BA, BB, NA, NB)                                                                                           \
   do {                                                                                                                    \
-    hipLaunchKernelGGL((conv_pair_kernel<BA, BB>), dim3((unsigned)((NA) + (NB))), dim3(BA::THREADS), 0, st, a, b,         \
+    DT_LAUNCH((conv_pair_kernel<BA, BB>), dim3((unsigned)((NA) + (NB))), dim3(BA::THREADS), 0, st, a, b,         \
                        (unsigned)(NA));                                                                                   \
     return check_launch("dt_conv2d_pair_f32");                                                                            \
   } while (0)
@@ -1574,7 +1574,7 @@ int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in0, const float* i
   DT_REQUIRE(d->c_out > 0, "dt_conv2d_simple_f32: c_out=%d", d->c_out);
   const size_t total = (size_t)a.n * a.h_out * a.w_out * a.c_out;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(conv_simple_kernel, dim3(blocks), dim3(256), 0, to_stream(s), a, W, d->ksize, d->stride);
+  DT_LAUNCH(conv_simple_kernel, dim3(blocks), dim3(256), 0, to_stream(s), a, W, d->ksize, d->stride);
   return check_launch("dt_conv2d_simple_f32");
 }
 
@@ -1583,7 +1583,7 @@ int dt_conv1x1_head_f32(const float* in, const float* w, const float* bias, floa
   DT_REQUIRE(in && w && out, "dt_conv1x1_head_f32: null pointer");
   DT_REQUIRE(pixels > 0 && c > 0 && c % 4 == 0, "dt_conv1x1_head_f32: bad extents pixels=%ld c=%d", (long)pixels, c);
   const int64_t threads = pixels * 4;
-  hipLaunchKernelGGL(conv1x1_head_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, to_stream(s), in, w, bias,
+  DT_LAUNCH(conv1x1_head_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, to_stream(s), in, w, bias,
                      out, out_exp, pixels, c);
   return check_launch("dt_conv1x1_head_f32");
 }
@@ -1593,7 +1593,7 @@ int dt_upsample2x_bilinear_f32(const float* in, float* out, int n, int h, int w,
   DT_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "dt_upsample2x_bilinear_f32: bad extents");
   const size_t total = (size_t)n * 4 * h * w * (c / 4);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(upsample2x_bilinear_kernel, dim3(blocks), dim3(256), 0, to_stream(s), in, out, n, h, w, c);
+  DT_LAUNCH(upsample2x_bilinear_kernel, dim3(blocks), dim3(256), 0, to_stream(s), in, out, n, h, w, c);
   return check_launch("dt_upsample2x_bilinear_f32");
 }
 

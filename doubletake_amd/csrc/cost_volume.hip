@@ -313,7 +313,7 @@ int dt_cv_setup_f32(const float* src_Ks, const float* src_ext, const float* src_
              num_src, num_planes);
   DT_REQUIRE(src_Ks && src_ext && src_poses && cur_invK && min_depth && max_depth && params_out,
              "dt_cv_setup_f32: null pointer");
-  hipLaunchKernelGGL(cv_setup_kernel, dim3(batch), dim3(64), 0, to_stream(s), src_Ks, src_ext, src_poses, cur_invK,
+  DT_LAUNCH(cv_setup_kernel, dim3(batch), dim3(64), 0, to_stream(s), src_Ks, src_ext, src_poses, cur_invK,
                      min_depth, max_depth, num_src, num_planes, params_out);
   return check_launch("dt_cv_setup_f32");
 }
@@ -326,7 +326,7 @@ int dt_cv_warp_f32(const float* src_bkchw, const float* params, const float* dep
              "dt_cv_warp_f32: null pointer");
   const size_t hw = (size_t)h * w;
   dim3 grid((unsigned)((hw + 255) / 256), num_src, batch);
-  hipLaunchKernelGGL(cv_warp_kernel, grid, dim3(256), 0, to_stream(s), src_bkchw, params, depth_bhw, num_src, channels, h, w,
+  DT_LAUNCH(cv_warp_kernel, grid, dim3(256), 0, to_stream(s), src_bkchw, params, depth_bhw, num_src, channels, h, w,
                      num_planes, world_points_B4N, depths_bkhw, warped_bkchw, mask_bkhw);
   return check_launch("dt_cv_warp_f32");
 }
@@ -344,7 +344,7 @@ int dt_cv_mlp_hint_simple_f32(const float* cur, const float* src, const float* p
              "dt_cv_mlp_hint_simple_f32: hint MLP given without hint maps");
   const size_t hw = (size_t)h * w;
   dim3 grid((unsigned)((hw + 127) / 128), num_planes, batch);
-  hipLaunchKernelGGL(cv_mlp_simple_kernel, grid, dim3(128), 0, to_stream(s), cur, src, params, W1, b1, W2, b2, W3, b3,
+  DT_LAUNCH(cv_mlp_simple_kernel, grid, dim3(128), 0, to_stream(s), cur, src, params, W1, b1, W2, b2, W3, b3,
                      hint_mlp, depth_hint, hint_w, hint_m, hint_h, hint_w2, vol, num_src, h, w, num_planes);
   return check_launch("dt_cv_mlp_hint_simple_f32");
 }
@@ -356,7 +356,7 @@ int dt_cv_lowest_cost_f32(const float* volume, const float* params, float* lowes
   const size_t hw = (size_t)h * w;
   const size_t threads = nhwc ? hw * 16 : hw;
   dim3 grid((unsigned)((threads + 255) / 256), batch);
-  hipLaunchKernelGGL(cv_lowest_cost_kernel, grid, dim3(256), 0, to_stream(s), volume, params, lowest, nhwc, num_src, hw,
+  DT_LAUNCH(cv_lowest_cost_kernel, grid, dim3(256), 0, to_stream(s), volume, params, lowest, nhwc, num_src, hw,
                      num_planes);
   return check_launch("dt_cv_lowest_cost_f32");
 }
@@ -367,7 +367,7 @@ int dt_cv_overall_mask_u8(const float* params, uint8_t* mask_out, int per_view, 
   DT_REQUIRE(params && mask_out, "dt_cv_overall_mask_u8: null pointer");
   const size_t hw = (size_t)h * w;
   dim3 grid((unsigned)((hw + 255) / 256), batch);
-  hipLaunchKernelGGL(cv_mask_kernel, grid, dim3(256), 0, to_stream(s), params, mask_out, per_view, num_src, h, w,
+  DT_LAUNCH(cv_mask_kernel, grid, dim3(256), 0, to_stream(s), params, mask_out, per_view, num_src, h, w,
                      num_planes);
   return check_launch("dt_cv_overall_mask_u8");
 }

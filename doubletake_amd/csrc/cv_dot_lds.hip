@@ -369,10 +369,10 @@ static int dot_launch(int mode, const float* cur, const float* src, const float*
   if (force_group >= 1 && force_group <= kDotMaxGroup) group = force_group;
   dim3 grid(wgs, (num_planes + group - 1) / group, batch);
   if (mode == 0)
-    hipLaunchKernelGGL(cv_dot_lds_kernel<0>, grid, dim3(64 * kDotWaves), 0, to_stream(s), cur, src, params, vol, num_src, h, w,
+    DT_LAUNCH(cv_dot_lds_kernel<0>, grid, dim3(64 * kDotWaves), 0, to_stream(s), cur, src, params, vol, num_src, h, w,
                        num_planes, group, stats);
   else
-    hipLaunchKernelGGL(cv_dot_lds_kernel<1>, grid, dim3(64 * kDotWaves), 0, to_stream(s), cur, src, params, vol, num_src, h, w,
+    DT_LAUNCH(cv_dot_lds_kernel<1>, grid, dim3(64 * kDotWaves), 0, to_stream(s), cur, src, params, vol, num_src, h, w,
                        num_planes, group, stats);
   return check_launch(what);
 }

@@ -528,7 +528,7 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
       (void)hipGetLastError();                                                                                     \
       return fail("dt_cv_mlp_hint_f32: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));          \
     }                                                                                                              \
-    hipLaunchKernelGGL((cv_mlp_mfma_kernel<HINT_, NW_>), dim3(blocks), dim3(NW_ * 64), lds_bytes, to_stream(s), a); \
+    DT_LAUNCH((cv_mlp_mfma_kernel<HINT_, NW_>), dim3(blocks), dim3(NW_ * 64), lds_bytes, to_stream(s), a); \
   } while (0)
   if (hint_mlp) {
     if (nw == 8) DT_LAUNCH_MLP(true, 8); else DT_LAUNCH_MLP(true, 4);

@@ -483,7 +483,7 @@ int dt_cv_mlp_hint_split_f32(const float* cur, const float* src, const float* pa
       (void)hipGetLastError();                                                                                       \
       return fail("dt_cv_mlp_hint_split_f32: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));      \
     }                                                                                                                \
-    hipLaunchKernelGGL((sp::cv_mlp_split_kernel<HINT_>), dim3(blocks), dim3(512), lds_bytes, to_stream(s), a);         \
+    DT_LAUNCH((sp::cv_mlp_split_kernel<HINT_>), dim3(blocks), dim3(512), lds_bytes, to_stream(s), a);         \
   } while (0)
   if (hint_mlp) DT_LAUNCH_SPLIT(true); else DT_LAUNCH_SPLIT(false);
 #undef DT_LAUNCH_SPLIT

@@ -291,7 +291,7 @@ int dt_stem_im2col_f32(const float* image_nchw, float* cols_nhwc, int n, int H, 
   DT_REQUIRE(n > 0 && H > 0 && W > 0, "dt_stem_im2col_f32: bad extents n=%d H=%d W=%d", n, H, W);
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const size_t total = (size_t)n * Ho * Wo * (kStemCols / 4);
-  hipLaunchKernelGGL(stem_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(s), image_nchw, cols_nhwc, n, H, W,
+  DT_LAUNCH(stem_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(s), image_nchw, cols_nhwc, n, H, W,
                      Ho, Wo);
   return check_launch("dt_stem_im2col_f32");
 }
@@ -304,7 +304,7 @@ int dt_maxpool_f32(const float* in, float* out, int n, int h, int w, int c, int 
   const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
   DT_REQUIRE(ho > 0 && wo > 0, "dt_maxpool_f32: empty output");
   const size_t total = (size_t)n * ho * wo * (c / 4);
-  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(s), in, out, n, h, w, c, ho, wo, ksize,
+  DT_LAUNCH(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(s), in, out, n, h, w, c, ho, wo, ksize,
                      stride, pad);
   return check_launch("dt_maxpool_f32");
 }
@@ -316,7 +316,7 @@ int dt_blurpool4_s2_f32(const float* in, float* out, const float* filt16_host, i
   BlurFilt f;
   for (int i = 0; i < 16; ++i) f.f[i] = filt16_host[i];
   const size_t total = (size_t)n * ho * wo * (c / 4);
-  hipLaunchKernelGGL(blurpool_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(s), in, out, n, h, w, c, ho, wo, f);
+  DT_LAUNCH(blurpool_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(s), in, out, n, h, w, c, ho, wo, f);
   return check_launch("dt_blurpool4_s2_f32");
 }
 
@@ -328,7 +328,7 @@ int dt_maxblur_f32(const float* in, float* out, const float* filt16_host, int n,
   BlurFilt f;
   for (int i = 0; i < 16; ++i) f.f[i] = filt16_host[i];
   const size_t total = (size_t)n * ho * wo * (c / 4);
-  hipLaunchKernelGGL(maxblur_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(s), in, out, n, h, w, c, ho, wo, f);
+  DT_LAUNCH(maxblur_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(s), in, out, n, h, w, c, ho, wo, f);
   return check_launch("dt_maxblur_f32");
 }
 
@@ -348,10 +348,10 @@ int dt_instnorm_f32(const float* in, float* out, void* workspace, int n, int hw,
   double* part = reinterpret_cast<double*>(workspace);
   float* stats = reinterpret_cast<float*>(part + (size_t)n * chunks * c * 2);
   hipStream_t st = to_stream(s);
-  hipLaunchKernelGGL(instnorm_partial_kernel, dim3(chunks, n), dim3(256), 0, st, in, part, hw, c, c_stride, chunks);
-  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((n * c + 3) / 4), dim3(256), 0, st, part, stats, n, hw, c, chunks, eps);
+  DT_LAUNCH(instnorm_partial_kernel, dim3(chunks, n), dim3(256), 0, st, in, part, hw, c, c_stride, chunks);
+  DT_LAUNCH(instnorm_finalize_kernel, dim3((n * c + 3) / 4), dim3(256), 0, st, part, stats, n, hw, c, chunks, eps);
   const size_t total = out_nchw ? (size_t)n * hw * c : (size_t)n * hw * (c / 4);
-  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, stats, out, n, hw, c, c_stride, act,
+  DT_LAUNCH(instnorm_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, stats, out, n, hw, c, c_stride, act,
                      out_nchw);
   return check_launch("dt_instnorm_f32");
 }
@@ -473,7 +473,7 @@ int dt_stem_pack_floats(void) { return 2 * dt::kStemSteps * 64; }
 
 int dt_stem_pack_f32(const float* W_64x3x7x7, float* packed, dt_stream_t s) {
   DT_REQUIRE(W_64x3x7x7 && packed, "dt_stem_pack_f32: null pointer");
-  hipLaunchKernelGGL(dt::stem_pack_kernel, dim3((2 * dt::kStemSteps * 64 + 255) / 256), dim3(256), 0, dt::to_stream(s),
+  DT_LAUNCH(dt::stem_pack_kernel, dim3((2 * dt::kStemSteps * 64 + 255) / 256), dim3(256), 0, dt::to_stream(s),
                      W_64x3x7x7, packed);
   return dt::check_launch("dt_stem_pack_f32");
 }
@@ -488,7 +488,7 @@ int dt_stem_conv_f32(const float* image_nchw, const float* packed_w, const float
   const long pairs = (tiles + 1) / 2;
   const int cus = dt::device_cu_count();
   const long want = (long)cus * 3;  // 148 VGPRs -> three workgroups per CU
-  hipLaunchKernelGGL(dt::stem_conv_kernel, dim3((unsigned)(pairs < want ? pairs : want)), dim3(256), 0, dt::to_stream(s),
+  DT_LAUNCH(dt::stem_conv_kernel, dim3((unsigned)(pairs < want ? pairs : want)), dim3(256), 0, dt::to_stream(s),
                      image_nchw, packed_w, bias64, out_nhwc, n, H, W, Ho, Wo, act);
   return dt::check_launch("dt_stem_conv_f32");
 }

@@ -261,11 +261,11 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
   static const long split_max_tiles = [] { const char* e = getenv("DT_HEAD_SPLIT_MAX_TILES"); return e ? atol(e) : kHeadSplitMaxTiles; }();
   if (tiles <= split_max_tiles) {  // small image: one tile per workgroup, hidden features split over the waves
     if (cin == 64)
-      hipLaunchKernelGGL(head_mlp_split_kernel<8>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
+      DT_LAUNCH(head_mlp_split_kernel<8>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
     else if (cin == 128)
-      hipLaunchKernelGGL(head_mlp_split_kernel<16>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
+      DT_LAUNCH(head_mlp_split_kernel<16>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
     else
-      hipLaunchKernelGGL(head_mlp_split_kernel<32>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
+      DT_LAUNCH(head_mlp_split_kernel<32>, dim3((unsigned)tiles), dim3(256), 0, to_stream(s), a);
     return check_launch("dt_head_mlp_f32");
   }
   DT_REQUIRE(cin != 256, "dt_head_mlp_f32: cin=256 is only supported up to %ld pixel tiles (got %ld)", split_max_tiles, tiles);
@@ -280,7 +280,7 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
       (void)hipGetLastError();                                                                                       \
       return fail("dt_head_mlp_f32: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));               \
     }                                                                                                                \
-    hipLaunchKernelGGL(head_mlp_kernel<NG_>, dim3(blocks), dim3(256), lds_bytes, to_stream(s), a);                   \
+    DT_LAUNCH(head_mlp_kernel<NG_>, dim3(blocks), dim3(256), lds_bytes, to_stream(s), a);                   \
   } while (0)
   if (cin == 64) DT_LAUNCH_HEAD(8); else DT_LAUNCH_HEAD(16);
 #undef DT_LAUNCH_HEAD
@@ -309,7 +309,7 @@ int dt_head_mlp_multi_f32(int n_heads, const float* const* in_nhwc, const float*
   }
   m.first[kHeadMultiMax] = total;
   for (int i = n_heads; i < kHeadMultiMax; ++i) m.first[i] = 0xffffffffu;  // never selected
-  hipLaunchKernelGGL(head_mlp_multi_kernel, dim3(total), dim3(256), 0, to_stream(s), m);
+  DT_LAUNCH(head_mlp_multi_kernel, dim3(total), dim3(256), 0, to_stream(s), m);
   return check_launch("dt_head_mlp_multi_f32");
 }
 

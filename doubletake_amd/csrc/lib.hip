@@ -1,4 +1,5 @@
 // Library-level entry points: version, error text, device count, layout helpers, exp.
+#include <atomic>
 #include <map>
 #include <mutex>
 
@@ -18,6 +19,9 @@ int fail(const char* fmt, ...) {
   va_end(ap);
   return 1;
 }
+
+static std::atomic<long long> g_launches{0};
+void note_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 
 int device_cu_count() {
   static std::mutex mtx;
@@ -69,7 +73,7 @@ __global__ void exp_kernel(const float* __restrict__ in, float* __restrict__ out
 
 static int transpose_last2(const float* src, float* dst, int n, int rows, int cols, hipStream_t s) {
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, n);
-  hipLaunchKernelGGL(transpose_last2_kernel, grid, dim3(256), 0, s, src, dst, rows, cols);
+  DT_LAUNCH(transpose_last2_kernel, grid, dim3(256), 0, s, src, dst, rows, cols);
   return check_launch("transpose");
 }
 
@@ -82,6 +86,8 @@ extern "C" {
 int dt_version(void) { return 101; }
 
 const char* dt_last_error(void) { return err_buf(); }
+
+int64_t dt_kernel_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
 
 int dt_device_count(void) {
   int n = 0;
@@ -108,7 +114,7 @@ int dt_exp_f32(const float* in, float* out, int64_t count, dt_stream_t s) {
   DT_REQUIRE(in && out && count >= 0, "dt_exp_f32: bad arguments");
   if (count == 0) return 0;
   const int blocks = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
-  hipLaunchKernelGGL(exp_kernel, dim3(blocks), dim3(256), 0, to_stream(s), in, out, count);
+  DT_LAUNCH(exp_kernel, dim3(blocks), dim3(256), 0, to_stream(s), in, out, count);
   return check_launch("dt_exp_f32");
 }
 

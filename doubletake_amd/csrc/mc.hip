@@ -250,8 +250,8 @@ int dt_mc_count(const uint16_t* values, const uint32_t* active, int X, int Y, in
   DT_REQUIRE(nblocks < 2147483647ull, "dt_mc_count: volume too large");
   int* sums = reinterpret_cast<int*>(workspace);
   int* cells = sums + nblocks;
-  hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, to_stream(s), a, sums, cells);
-  hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, to_stream(s), sums, cells, (int)nblocks, counts_out);
+  DT_LAUNCH(mc_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, to_stream(s), a, sums, cells);
+  DT_LAUNCH(mc_scan_kernel, dim3(1), dim3(1024), 0, to_stream(s), sums, cells, (int)nblocks, counts_out);
   return check_launch("dt_mc_count");
 }
 
@@ -265,7 +265,7 @@ int dt_mc_generate(const uint16_t* values, const uint32_t* active, int X, int Y,
   if (num_verts == 0) return 0;
   DT_REQUIRE(verts && faces && ids, "dt_mc_generate: null output");
   const size_t nblocks = (size_t)X * Y * Z / 256;
-  hipLaunchKernelGGL(mc_generate_kernel, dim3((unsigned)nblocks), dim3(256), 0, to_stream(s), a,
+  DT_LAUNCH(mc_generate_kernel, dim3((unsigned)nblocks), dim3(256), 0, to_stream(s), a,
                      reinterpret_cast<const int*>(workspace), verts, faces, ids, num_verts);
   return check_launch("dt_mc_generate");
 }

@@ -122,11 +122,11 @@ int dt_raster_depth_f32(const float* verts_v3, const int64_t* faces_f3, int64_t 
   DT_REQUIRE(num_faces == 0 || (verts_v3 && faces_f3), "dt_raster_depth_f32: null mesh");
   const int64_t n = (int64_t)h * w;
   hipStream_t st = to_stream(s);
-  hipLaunchKernelGGL(raster_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, n);
+  DT_LAUNCH(raster_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, n);
   if (num_faces > 0)
-    hipLaunchKernelGGL(raster_faces_kernel, dim3((unsigned)((num_faces + 127) / 128)), dim3(128), 0, st, verts_v3, faces_f3,
+    DT_LAUNCH(raster_faces_kernel, dim3((unsigned)((num_faces + 127) / 128)), dim3(128), 0, st, verts_v3, faces_f3,
                        num_faces, cam_T_world_44, K_44, h, w, workspace_hw);
-  hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, depth_hw, n);
+  DT_LAUNCH(raster_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, depth_hw, n);
   return check_launch("dt_raster_depth_f32");
 }
 
@@ -138,11 +138,11 @@ int dt_raster_soup_depth_f32(const float* verts_kji_v3, int64_t num_faces, const
   DT_REQUIRE(num_faces == 0 || verts_kji_v3, "dt_raster_soup_depth_f32: null mesh");
   const int64_t n = (int64_t)h * w;
   hipStream_t st = to_stream(s);
-  hipLaunchKernelGGL(raster_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, n);
+  DT_LAUNCH(raster_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, n);
   if (num_faces > 0)
-    hipLaunchKernelGGL(raster_soup_kernel, dim3((unsigned)((num_faces + 127) / 128)), dim3(128), 0, st, verts_kji_v3, num_faces,
+    DT_LAUNCH(raster_soup_kernel, dim3((unsigned)((num_faces + 127) / 128)), dim3(128), 0, st, verts_kji_v3, num_faces,
                        origin3[0], origin3[1], origin3[2], voxel_size, cam_T_world_44, K_44, h, w, workspace_hw);
-  hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, depth_hw, n);
+  DT_LAUNCH(raster_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, depth_hw, n);
   return check_launch("dt_raster_soup_depth_f32");
 }
 

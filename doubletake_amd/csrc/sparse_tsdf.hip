@@ -437,10 +437,10 @@ static int integrate_one(const SpGrid& g, const SpCamSrc& cam, const float* dept
                          float trunc_voxels, int extended_neg_truncation, hipStream_t st) {
   const float trunc = trunc_voxels * g.voxel_size;
   const int n = (img_h / 4) * (img_w / 4);
-  hipLaunchKernelGGL(sp_touch_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, cam, depth_hw, img_h, img_w, max_depth, trunc);
-  hipLaunchKernelGGL(sp_allocate_kernel, dim3(1), dim3(1024), 0, st, g);
+  DT_LAUNCH(sp_touch_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, cam, depth_hw, img_h, img_w, max_depth, trunc);
+  DT_LAUNCH(sp_allocate_kernel, dim3(1), dim3(1024), 0, st, g);
   const int wgs = g.cap < 2048 ? g.cap : 2048;
-  hipLaunchKernelGGL(sp_integrate_kernel, dim3(wgs), dim3(256), 0, st, g, cam, depth_hw, img_h, img_w, max_depth, trunc,
+  DT_LAUNCH(sp_integrate_kernel, dim3(wgs), dim3(256), 0, st, g, cam, depth_hw, img_h, img_w, max_depth, trunc,
                      extended_neg_truncation ? -1.5f * trunc : -trunc);
   return 0;
 }
@@ -496,7 +496,7 @@ int dt_sparse_sample_f32(int* dir, unsigned char* touch, int nb, float voxel_siz
   if (int rc = fill_grid(g, dir, touch, nb, voxel_size, keys, tsdf, weight, count2, capacity, "dt_sparse_sample_f32")) return rc;
   DT_REQUIRE(points_N3 && out_N && n >= 0 && (what == 0 || what == 1), "dt_sparse_sample_f32: bad arguments");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(sp_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, to_stream(s), g, points_N3, out_N, (long)n,
+  DT_LAUNCH(sp_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, to_stream(s), g, points_N3, out_N, (long)n,
                      what);
   return check_launch("dt_sparse_sample_f32");
 }
@@ -508,8 +508,8 @@ int dt_sparse_mc_count(int* dir, unsigned char* touch, int nb, float voxel_size,
   SpGrid g;
   if (int rc = fill_grid(g, dir, touch, nb, voxel_size, keys, tsdf, weight, count2, capacity, "dt_sparse_mc_count")) return rc;
   DT_REQUIRE(slot_offsets && total_out && num_slots > 0 && num_slots <= capacity, "dt_sparse_mc_count: bad arguments");
-  hipLaunchKernelGGL(sp_mc_count_kernel, dim3(num_slots), dim3(256), 0, to_stream(s), g, isolevel, weight_threshold, slot_offsets);
-  hipLaunchKernelGGL(sp_mc_scan_kernel, dim3(1), dim3(1024), 0, to_stream(s), slot_offsets, num_slots, total_out);
+  DT_LAUNCH(sp_mc_count_kernel, dim3(num_slots), dim3(256), 0, to_stream(s), g, isolevel, weight_threshold, slot_offsets);
+  DT_LAUNCH(sp_mc_scan_kernel, dim3(1), dim3(1024), 0, to_stream(s), slot_offsets, num_slots, total_out);
   return check_launch("dt_sparse_mc_count");
 }
 
@@ -522,7 +522,7 @@ int dt_sparse_mc_generate(int* dir, unsigned char* touch, int nb, float voxel_si
   DT_REQUIRE(num_verts >= 0 && num_verts % 3 == 0, "dt_sparse_mc_generate: num_verts=%d", num_verts);
   if (num_verts == 0) return 0;
   DT_REQUIRE(verts && faces && ids, "dt_sparse_mc_generate: null output");
-  hipLaunchKernelGGL(sp_mc_generate_kernel, dim3(num_slots), dim3(256), 0, to_stream(s), g, isolevel, weight_threshold,
+  DT_LAUNCH(sp_mc_generate_kernel, dim3(num_slots), dim3(256), 0, to_stream(s), g, isolevel, weight_threshold,
                      slot_offsets, verts, vert_weights, faces, ids, num_verts);
   return check_launch("dt_sparse_mc_generate");
 }

@@ -329,7 +329,7 @@ int dt_tsdf_frames_setup_f16(const uint16_t* K16, const uint16_t* T16, int num_f
                              float depth_min, float depth_max, float* frame_params, dt_stream_t s) {
   DT_REQUIRE(K16 && T16 && frame_params, "dt_tsdf_frames_setup_f16: null pointer");
   DT_REQUIRE(img_h > 0 && img_w > 0 && num_frames > 0, "dt_tsdf_frames_setup_f16: bad extents");
-  hipLaunchKernelGGL(tsdf_frame_setup_kernel, dim3(num_frames), dim3(64), 0, to_stream(s), K16, T16, img_h, img_w, depth_min,
+  DT_LAUNCH(tsdf_frame_setup_kernel, dim3(num_frames), dim3(64), 0, to_stream(s), K16, T16, img_h, img_w, depth_min,
                      depth_max, frame_params);
   return check_launch("dt_tsdf_frames_setup_f16");
 }
@@ -373,10 +373,10 @@ static int integrate_frames(uint16_t* values, uint16_t* weights, uint32_t* activ
   DT_REQUIRE(X <= 65535 && slab < 4294967040ull, "dt_tsdf_integrate_f16: volume too large for one launch");
   const dim3 grid((unsigned)((slab + 255) / 256), (unsigned)X);
   if (depth32)
-    hipLaunchKernelGGL(tsdf_integrate_kernel<true>, grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, img_h,
+    DT_LAUNCH(tsdf_integrate_kernel<true>, grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, img_h,
                        img_w, frame_params, num_frames, c);
   else
-    hipLaunchKernelGGL(tsdf_integrate_kernel<false>, grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, img_h,
+    DT_LAUNCH(tsdf_integrate_kernel<false>, grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, img_h,
                        img_w, frame_params, num_frames, c);
   return check_launch("dt_tsdf_integrate_f16");
 }
@@ -400,7 +400,7 @@ int dt_tsdf_sample_f16(const uint16_t* volume, const float* origin3, float voxel
   DT_REQUIRE(volume && origin3 && points_n3 && out_n, "dt_tsdf_sample_f16: null pointer");
   DT_REQUIRE(X > 1 && Y > 1 && Z > 1 && n >= 0 && voxel_size > 0.f, "dt_tsdf_sample_f16: bad extents");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(tsdf_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, to_stream(s), volume, origin3[0],
+  DT_LAUNCH(tsdf_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, to_stream(s), volume, origin3[0],
                      origin3[1], origin3[2], voxel_size, X, Y, Z, points_n3, out_n, n, fp16_math);
   return check_launch("dt_tsdf_sample_f16");
 }
@@ -413,7 +413,7 @@ int dt_hint_from_depth_f32(const float* depth_hw, const uint16_t* weights_vol_f1
                  mask_b_hw && sampled_weights_hw,
              "dt_hint_from_depth_f32: null pointer");
   DT_REQUIRE(X > 1 && Y > 1 && Z > 1 && h > 0 && w > 0 && voxel_size > 0.f, "dt_hint_from_depth_f32: bad extents");
-  hipLaunchKernelGGL(hint_from_depth_kernel, dim3((unsigned)((h * w + 255) / 256)), dim3(256), 0, to_stream(s), depth_hw,
+  DT_LAUNCH(hint_from_depth_kernel, dim3((unsigned)((h * w + 255) / 256)), dim3(256), 0, to_stream(s), depth_hw,
                      weights_vol_f16, origin3[0], origin3[1], origin3[2], voxel_size, X, Y, Z, invK_44, world_T_cam_44, threshold, h, w, hint_hw,
                      mask_hw, mask_b_hw, sampled_weights_hw);
   return check_launch("dt_hint_from_depth_f32");

@@ -17,6 +17,17 @@ from .. import _abi
 ACT_NONE, ACT_LRELU02, ACT_ELU, ACT_RELU = 0, 1, 2, 3
 
 
+#: optional accounting of the work launched through this module (bench.py ``roofline_conv``): set to a dict with the
+#: keys "flops" / "calls" and every op adds its direct-convolution-equivalent FLOPs (2 * outputs * K) to it
+ACCOUNT = None
+
+
+def _account(flops):
+    if ACCOUNT is not None:
+        ACCOUNT["flops"] += float(flops)
+        ACCOUNT["calls"] += 1
+
+
 def _require_gpu(t, name="input"):
     if not t.is_cuda:
         raise _abi.DoubletakeHipError(
@@ -175,6 +186,7 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
     if residual is not None and (not _is_nhwc(residual) or tuple(residual.shape) != tuple(out.shape)):
         raise ValueError("residual must be NHWC with the output's shape")
     stream = _abi.current_stream(dev)
+    _account(2.0 * n * d.h_out * d.w_out * co * ctot * k * k)
     if impl == "mfma" and (co % 32 != 0 or any(d.c[i] % 8 != 0 for i in range(len(srcs)))):
         # channel counts the 32-channel x 8-channel-group MFMA tiling cannot express (the reference's own
         # configurations never produce them): the general-shape kernel, same fused epilogue
@@ -251,6 +263,8 @@ def conv2d_pair(srcs, conv_a: nn.Conv2d, act_a, conv_b: nn.Conv2d, act_b):
     wb = packed_weight(conv_b, dev, transposed=bool(db.transposed))
     out_a = empty_nhwc(da.n, co_a, da.h_out, da.w_out, dev)
     out_b = empty_nhwc(db.n, co_b, db.h_out, db.w_out, dev)
+    cin = sum(t.shape[1] for t, _ in srcs)
+    _account(2.0 * da.n * da.h_out * da.w_out * cin * (co_a * ka * ka + co_b * kb * kb))
     _abi.check(L.dt_conv2d_pair_f32(C.byref(da), C.byref(db), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wa), int(a_wino),
                                     _abi.ptr(_dev_param(conv_a, "bias", dev)), _abi.ptr(out_a), _abi.ptr(wb),
                                     _abi.ptr(_dev_param(conv_b, "bias", dev)), _abi.ptr(out_b), _abi.current_stream(dev)),
@@ -270,6 +284,7 @@ def conv1x1_head(x, conv: nn.Conv2d, with_exp=False):
     wv = _dev_param(conv, "weight", dev)
     b = _dev_param(conv, "bias", dev)
     out_e = torch.empty_like(out) if with_exp else None
+    _account(2.0 * n * h * w * c)
     _abi.check(L.dt_conv1x1_head_f32(_abi.ptr(x), _abi.ptr(wv), _abi.ptr(b), _abi.ptr(out), _abi.ptr(out_e), n * h * w, c,
                                      _abi.current_stream(dev)), "dt_conv1x1_head_f32")
     return (out, out_e) if with_exp else out
@@ -309,6 +324,7 @@ def head_mlp_multi(xs, heads, with_exp=False):
     tab = lambda vals: (C.c_void_p * n_h)(*[_abi.ptr(v) for v in vals])
     pixels = (C.c_int64 * n_h)(*[x.shape[0] * x.shape[2] * x.shape[3] for x in xs])
     cin = (C.c_int * n_h)(*[x.shape[1] for x in xs])
+    _account(sum(2.0 * x.shape[0] * x.shape[2] * x.shape[3] * (x.shape[1] * 128 + 128 * 128 + 128) for x in xs))
     _abi.check(L.dt_head_mlp_multi_f32(n_h, tab(xs), tab([p["wa"] for p in pks]), tab([p["wb"] for p in pks]),
                                        tab([p["tail"] for p in pks]), tab(outs), tab(outs_e), pixels, cin,
                                        _abi.current_stream(dev)), "dt_head_mlp_multi_f32")
@@ -324,6 +340,7 @@ def head_mlp(x, head: nn.Sequential, with_exp=False):
     pk = _head_pack(head, dev)
     out = torch.empty((n, 1, h, w), device=dev, dtype=torch.float32)
     out_e = torch.empty_like(out) if with_exp else None
+    _account(2.0 * n * h * w * (c * 128 + 128 * 128 + 128))
     _abi.check(L.dt_head_mlp_f32(_abi.ptr(x), _abi.ptr(pk["wa"]), _abi.ptr(pk["wb"]), _abi.ptr(pk["tail"]), _abi.ptr(out),
                                  _abi.ptr(out_e), n * h * w, c, _abi.current_stream(dev)), "dt_head_mlp_f32")
     return (out, out_e) if with_exp else out

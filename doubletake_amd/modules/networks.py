@@ -131,7 +131,9 @@ class DepthDecoderPP(nn.Module):
                 )
 
     @torch.no_grad()
-    def forward(self, input_features, _impl="mfma"):
+    def forward(self, input_features, _impl="mfma", _nodes=None):
+        """_nodes: optional dict that receives the UNet++ node outputs X_ij under their ModuleDict names
+        (``in_conv_{i}{j}``) -- what a forward hook on the reference's ``convs[name]`` sees (parity tests)."""
         prev = [ops.as_nhwc(f) for f in input_features]
         outputs = []
         pending = {}
@@ -144,6 +146,8 @@ class DepthDecoderPP(nn.Module):
                     u = self.convs[f"up_conv_{i + 1}{j}"].run([(outputs[-1], False)], impl=_impl)
                     srcs.append((ops.upsample2x_bilinear(u), False))
                 out = _run_seq(self.convs[f"in_conv_{i}{j}"], srcs, impl=_impl)
+                if _nodes is not None:
+                    _nodes[f"in_conv_{i}{j}"] = out
                 outputs.append(out)
                 # the reference evaluates output_i for every j and keeps the last (networks.py:83);
                 # only the surviving evaluation is computed here.

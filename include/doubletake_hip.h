@@ -32,6 +32,9 @@ int dt_version(void);
 const char* dt_last_error(void);
 /* number of HIP devices visible; <0 on runtime error.  No other call needs it. */
 int dt_device_count(void);
+/* Kernels launched by this library in this process so far (all streams, all entry points): lets a caller report the
+ * launch count of a step as the difference of two reads (bench.py roofline_conv.launches). */
+int64_t dt_kernel_launch_count(void);
 
 /* ---- layout helpers (boundary between torch NCHW tensors and the kernels' NHWC) ------ */
 int dt_nchw_to_nhwc_f32(const float* src, float* dst, int n, int c, int h, int w, dt_stream_t s);

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Refresh profiles/roofline_traffic.json -- the HBM bytes per launch of cv_mlp_mfma_kernel that bench.py reports as
+roofline.traffic -- from a PMC summary written by scripts/pmc_summary.py.
+
+    python scripts/make_roofline_traffic.py r3c        # reads profiles/r3c_pmc_summary.json
+
+The record carries the hash of the kernel source the counters were collected on; bench.py reports the figure only while
+that hash equals the source it runs (so a stale pass can never be attributed to a newer kernel).  Run this after every
+PMC pass over bench.py (the line kept quoting an older pass although a newer one existed)."""
+import hashlib
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1]
+    summ = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")))
+    name = next(k for k in summ if "cv_mlp_mfma_kernel" in k)
+    rec = summ[name]
+    fetch_kb, write_kb = rec["FETCH_SIZE"], rec["WRITE_SIZE"]
+    src = open(os.path.join(REPO, "doubletake_amd", "csrc", "cv_mlp_mfma.hip"), "rb").read()
+    out = {
+        "profile_tag": tag,
+        "kernel": name,
+        "kernel_source_sha16": hashlib.sha256(src).hexdigest()[:16],
+        "cv_mlp_mfma_kernel_hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+        "FETCH_SIZE_KB": fetch_kb,
+        "WRITE_SIZE_KB": write_kb,
+        "source": f"profiles/{tag}_pmc_summary.json (scripts/collect_pmc.sh {tag}: one rocprofv3 --pmc pass per counter over "
+                  "bench.py --streams 1, means per dispatch)",
+        "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads -> doubled "
+                      "(MI355X_MICROARCH.md, HBM); Infinity-Cache hits are included in the counter; WRITE_SIZE uncorrected",
+        "algorithmic_bytes_per_launch": 15670000.0,
+        "note": "bench.py reports this figure only while kernel_source_sha16 equals the hash of "
+                "doubletake_amd/csrc/cv_mlp_mfma.hip (otherwise traffic = null: the kernel changed since the counters were collected)",
+    }
+    json.dump(out, open(os.path.join(REPO, "profiles", "roofline_traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

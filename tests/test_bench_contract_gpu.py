@@ -31,6 +31,28 @@ def test_bench_json_contract():
     assert rf["traffic"] is None or rf["traffic"] > 1e6
     dot = d["roofline_warp_match_dot"]
     assert dot["bound"] == "hbm" and dot["unit"] == "GB/s" and dot["peak"] == 8000.0
+    assert 0.0 < dot["valu_frac"] < 1.0 and 0.0 < dot["lds_frac"] < 1.0 and 0.0 < dot["batch8_512x384"]["lds_frac"] < 1.0
+    rc = d["roofline_conv"]  # conv stack + heads next to the dominant kernel
+    assert rc["bound"] == "mfma" and rc["peak"] == rf["peak"] and abs(rc["frac"] - rc["achieved"] / rc["peak"]) < 1e-9
+    assert 7.0e10 < rc["direct_equivalent_flops_per_step"] < 8.5e10   # CVEncoder 37.0 G + SkipDecoder/heads 40.7 G
+    assert 10 <= rc["launches"] <= 60 and rc["model_launches_per_step"] > rc["launches"]
+    assert d["config"]["name"] == "cfg2_small"
+
+
+def test_bench_other_baseline_shape_prints_the_same_contract():
+    """bench.py --config: the other BASELINE.json shapes through the same timed loop and JSON line (full model here)."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--config", "cfg5_full_d96", "--steps", "3", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["config"]["name"] == "cfg5_full_d96" and "DepthDecoderPP" in d["config"]["workload"]
+    assert d["config"]["frames_per_step_per_gpu"] == 2 and d["config"]["matching_resolution"] == [128, 96]
+    assert abs(d["value"] - 2e3 / d["ms_per_step"]) / d["value"] < 1e-6
+    assert d["cpu_baseline"] is None and "roofline_warp_match_dot" not in d
+    assert d["roofline"]["bound"] == "mfma" and 0.3 < d["roofline"]["frac"] < 1.0
+    assert d["roofline_conv"]["direct_equivalent_flops_per_step"] > 3e11   # 2 frames x (34.6 G + 292.1 G) x (96x128 / 120x160)
 
 
 def test_two_stream_frame_pipelining_is_bit_identical():

@@ -35,7 +35,16 @@ def build_case(name):
     gu.set_formula_weights(model.cost_volume.mlp, seed + 1)
     gu.set_formula_weights(model.cost_volume.hint_mlp, seed + 2)
     gu.set_formula_weights(model.cost_volume_net, seed + 3)
-    gu.set_formula_weights(model.depth_decoder, seed + 4, scale_mult=0.7 if dec == "unet_pp" else 1.0)
+    gu.set_formula_weights(model.depth_decoder, seed + 4)
+    if dec == "unet_pp":
+        # head gains / biases of the fixture (make_golden.py:gen_model_fullsize): log depth ~ zero mean, std 0.4 per scale,
+        # so depth spans about 0.2 .. 6 m and the tolerances below are small against the signal
+        g = load_golden("model_fullsize_checksums.npz")
+        with torch.no_grad():
+            for i in range(4):
+                head = model.depth_decoder.convs[f"output_{i}"][1]
+                head.weight.mul_(float(g[f"{name}|pp_head_gain"][i]))
+                head.bias.fill_(float(g[f"{name}|pp_head_bias"][i]))
     model = model.to(gu.dev())
     inp = syn.volume_inputs(b, k, h, w, 16, seed)
     t = gu.to_dev(inp)
@@ -78,8 +87,10 @@ def test_whole_model_against_reference_fullsize_checksums(name):
     for i in range(4):
         ld = out[f"log_depth_pred_s{i}_b1hw"]
         assert tuple(ld.shape) == (b, 1, (2 * h) >> i, (2 * w) >> i)
-        _check(g, name, f"log_depth_pred_s{i}_b1hw", ld.cpu().numpy(), 5e-4)
+        _check(g, name, f"log_depth_pred_s{i}_b1hw", ld.cpu().numpy(), 2e-4)
         _check(g, name, f"depth_pred_s{i}_b1hw", out[f"depth_pred_s{i}_b1hw"].cpu().numpy(), 1e-3)  # north-star tolerance
+    # the fixture has real dynamic range (round 2's UNet++ cases spanned < 0.1 in log depth)
+    assert float(g[f"{name}|depth_pred_s0_b1hw|max"]) / float(g[f"{name}|depth_pred_s0_b1hw|min"]) > 10.0
     # the argmax plane can flip between two nearly equal scores: allow isolated probes
     _check(g, name, "lowest_cost", out["lowest_cost_bhw"].cpu().numpy(), 1e-5, frac_ok=0.02)
     m = out["overall_mask_bhw"]
@@ -119,3 +130,66 @@ def test_whole_model_split_precision_mode_within_depth_tolerance(name):
     for i in range(4):
         _check(g, name, f"depth_pred_s{i}_b1hw", out[f"depth_pred_s{i}_b1hw"].cpu().numpy(), 1e-3)
         _check(g, name, f"log_depth_pred_s{i}_b1hw", out[f"log_depth_pred_s{i}_b1hw"].cpu().numpy(), 5e-4)
+
+
+PP_NODES = ("in_conv_31", "in_conv_22", "in_conv_13", "in_conv_01", "in_conv_02", "in_conv_03", "in_conv_04")
+
+
+def _run_decoder_nodes(name):
+    """DepthDecoderPP alone on the CVEncoder maps of the case: (node outputs, head outputs, model, inputs)."""
+    import gpu_util as gu
+
+    model, inp, t, pyr = build_case(name)
+    md, Md = (torch.tensor(v, device=gu.dev()).view(1, 1, 1, 1) for v in (model.min_matching_depth, model.max_matching_depth))
+    vol, _, _, _ = model.cost_volume(cur_feats=t["cur_feats"], src_feats=t["src_feats"], src_extrinsics=t["src_extrinsics"],
+                                     src_poses=t["src_poses"], src_Ks=t["src_Ks"], cur_invK=t["cur_invK"], min_depth=md,
+                                     max_depth=Md, return_mask=False, cv_depth_hint_dict=gu.hint_dict(t))
+    feats = [pyr[0]] + model.cost_volume_net(vol, pyr[1:])
+    return model, feats
+
+
+@pytest.mark.parametrize("name", ["cfg2_full", "cfg3_full_b8", "cfg5_full_d96"])
+def test_unetpp_node_outputs_against_reference_fullsize_checksums(name):
+    """The UNet++ decoder's node outputs X_ij (reference modules/networks.py:65-85, captured with forward hooks on
+    convs['in_conv_ij'] at full size) -- what cv_feat{i} is for the encoder: a wrong skip / diagonal / up input of any
+    node shows up here at O(0.5) against a 3e-4 tolerance, long before the heads."""
+    g = load_golden("model_fullsize_checksums.npz")
+    model, feats = _run_decoder_nodes(name)
+    nodes = {}
+    model.depth_decoder(feats, _nodes=nodes)
+    torch.cuda.synchronize()
+    assert set(PP_NODES) <= set(nodes)
+    for n in PP_NODES:
+        _check(g, name, f"pp_{n}", nodes[n].contiguous().cpu().numpy(), 3e-4)
+
+
+def test_fullsize_fixture_catches_a_swapped_skip_connection():
+    """Negative control: feed right_conv_02 -- the skip path of node X_03 -- the stale map
+    X_01 instead of X_02 (a one-character wiring slip in DepthDecoderPP.forward).  The full-size checks must fail."""
+    g = load_golden("model_fullsize_checksums.npz")
+    name = "cfg2_full"
+    model, feats = _run_decoder_nodes(name)
+    dec = model.depth_decoder
+    seen = {}
+    r01, r02 = dec.convs["right_conv_01"], dec.convs["right_conv_02"]
+    run01, run02 = r01.run, r02.run
+
+    def rec(srcs, impl="mfma"):
+        seen["x01"] = srcs
+        return run01(srcs, impl=impl)
+
+    r01.run = rec
+    r02.run = lambda srcs, impl="mfma": run02(seen["x01"], impl=impl)
+    try:
+        nodes = {}
+        out = dec(feats, _nodes=nodes)
+        torch.cuda.synchronize()
+    finally:
+        del r01.run, r02.run
+    _check(g, name, "pp_in_conv_02", nodes["in_conv_02"].contiguous().cpu().numpy(), 3e-4)  # upstream of the slip: still right
+    with pytest.raises(AssertionError):
+        _check(g, name, "pp_in_conv_03", nodes["in_conv_03"].contiguous().cpu().numpy(), 3e-4)
+    with pytest.raises(AssertionError):
+        _check(g, name, "log_depth_pred_s0_b1hw", out["log_depth_pred_s0_b1hw"].cpu().numpy(), 2e-4)
+    with pytest.raises(AssertionError):
+        _check(g, name, "depth_pred_s0_b1hw", torch.exp(out["log_depth_pred_s0_b1hw"]).cpu().numpy(), 1e-3)
