@@ -176,6 +176,51 @@ def test_two_pass_replicas_equal_serial_run(tmp_path):
             np.testing.assert_array_equal(got.view(np.uint16), want.view(np.uint16))  # bit-identical replicas
 
 
+# ---- bench.py's step order (two frames in flight on alternating streams) against the exchange ---------------------------
+def _bench_order_worker(rank, world, port, out_dir):
+    """bench.py issues step i from HIP stream i % 2; the collective of a step is enqueued from whichever stream runs it.
+    What has to hold for RCCL is that every rank issues the SAME sequence of collectives (same order, same shapes) and
+    integrates in the same canonical order -- the streams only change where the launch is enqueued.  Replayed here with the
+    stream of a step recorded instead of used; the schedule ends ragged (7 keyframes on 2 ranks)."""
+    _init(rank, world, port)
+    h, w = 6, 8
+    log, calls = [], []
+    real = dist.all_gather_into_tensor
+
+    def spy(out, inp, *a, **kw):
+        calls.append((tuple(out.shape), tuple(inp.shape), str(inp.dtype)))
+        return real(out, inp, *a, **kw)
+
+    par.dist.all_gather_into_tensor = spy
+    fuser = par.KeyframeShardFuser(torch.device("cpu"), world, rank, (h, w),
+                                   fuse_fn=lambda d, K, T: log.extend(float(v) for v in d[:, 0, 0, 0]))
+    nframes = 7
+    _, K, T = syn.tsdf_frames(8, h, w, seed=5, bounds=BD)
+    issue = []
+    for step in range((nframes + world - 1) // world):
+        stream = step % 2                       # bench.py: streams[frame_idx % len(streams)]
+        g = step * world + rank                 # bench.py: (frame_idx * world + rank) -> camera / keyframe index
+        counts = [1 if step * world + r < nframes else 0 for r in range(world)]
+        have = g < nframes
+        depth = torch.full((1, 1, h, w), float(g + 1)) if have else None
+        fuser.exchange_and_fuse(depth, torch.from_numpy(K[g:g + 1]) if have else None, torch.from_numpy(T[g:g + 1]) if have else None,
+                                counts=counts, rows=1)
+        issue.append((step, stream, tuple(counts)))
+    par.dist.all_gather_into_tensor = real
+    torch.save({"log": log, "calls": calls, "issue": issue}, os.path.join(out_dir, f"bo{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_bench_step_order_issues_identical_collectives_on_every_rank(tmp_path):
+    world = 2
+    _spawn(_bench_order_worker, world, str(tmp_path))
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"bo{r}.pt")) for r in range(world))
+    assert r0["calls"] == r1["calls"] and len(r0["calls"]) == 4          # one collective per step, same shapes, same order
+    assert r0["issue"] == r1["issue"] and [s for _, s, _ in r0["issue"]] == [0, 1, 0, 1]
+    assert r0["issue"][-1][2] == (1, 0)                                   # ragged last step: rank 1 has no keyframe
+    assert r0["log"] == r1["log"] == [float(i + 1) for i in range(7)]     # canonical (= serial) integration order on both
+
+
 # ---- revisit flow (test_revisit.py:104-260): first pass over a PREVIOUS scan, second pass over the new one -------------
 FIRST_SIZES = [2, 2, 1]          # the previous scan has its own (shorter, ragged) batch schedule
 REVISIT_SHIFT = np.array([[1, 0, 0, 0.10], [0, 1, 0, -0.05], [0, 0, 1, 0.0], [0, 0, 0, 1]], dtype=np.float32)

@@ -62,3 +62,66 @@ def test_world1_rccl_exchange_equals_serial_fuse():
         np.testing.assert_array_equal(got[0]["origin_f32"], b.origin_f32)
     finally:
         dist.destroy_process_group()
+
+
+def test_cfg5_size_two_pass_loop_through_the_collective_path():
+    """BASELINE configs[4] loop at its own size on one GPU with the RCCL exchange forced (world 1): portrait 384x512 frames,
+    96 planes, 7 source views, keyframe batches of 2 through loops.two_pass_fns + parallel.run_two_pass -- pass 1 with empty
+    hints, marching cubes, pass 2 with rendered hints -- every TSDF update travelling through all_gather_into_tensor.
+    The replicas must equal a run of the same loop without any collective, bit for bit."""
+    import torch.distributed as dist
+
+    import gpu_util as gu
+    import test_drivers_gpu as drv
+    from doubletake_amd import loops
+    from doubletake_amd import parallel as par
+    from doubletake_amd.tools.fusers_helper import OurFuser
+
+    dev = gu.dev()
+    torch.cuda.set_device(dev)
+    H, W, k, D, b, nb = 512, 384, 7, 96, 2, 3
+    H2, W2 = H // 2, W // 2
+    bd = drv.BD
+    model = drv._model(H, W, k, D, dev)
+    cams = drv._cams(b * nb, H2, W2)
+    surface, _, _ = syn.tsdf_frames(1, H2, W2, seed=3, bounds=bd)
+    base = torch.from_numpy(surface[0:1] * np.float32(0.55)).to(dev)
+    cover = []
+
+    def model_fn(cur_data, src_data):
+        out = model("test", cur_data, src_data, return_mask=True)
+        assert tuple(out["depth_pred_s0_b1hw"].shape) == (b, 1, H2, W2)
+        out["depth_pred_s0_b1hw"] = base + 0.02 * torch.tanh(out["depth_pred_s0_b1hw"] - 1.0)
+        cover.append(float(cur_data["depth_hint_mask_b1hw"].mean()))
+        return out
+
+    load = lambda i: drv._batch(i, b, k, H, W, dev, cams)
+
+    def run(force):
+        first, between, second = loops.two_pass_fns(model_fn, load, (H2, W2), fuse_size=(H, W))
+        hint_fuser, final_fuser = OurFuser(None, 0.04, 3.0, bounds=bd), OurFuser(None, 0.04, 3.0, bounds=bd)
+        sf_h = par.KeyframeShardFuser(dev, 1, 0, (H, W), fuser=hint_fuser, force_collective=force)
+        sf_f = par.KeyframeShardFuser(dev, 1, 0, (H, W), fuser=final_fuser, force_collective=force)
+        n = par.run_two_pass(nb, lambda i: b, first, second, sf_h, sf_f, between_passes=between)
+        torch.cuda.synchronize()
+        return n, hint_fuser.tsdf_fuser_pred.tsdf, final_fuser.tsdf_fuser_pred.tsdf, sf_f
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    s.close()
+    os.environ.pop("NCCL_DEBUG", None)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n_c, hint_c, final_c, sf = run(True)
+        assert sf._all is not None and sf._all.is_cuda and tuple(sf._all.shape) == (b, H * W + 32)   # really went through the gather
+    finally:
+        dist.destroy_process_group()
+    n_s, hint_s, final_s, _ = run(False)
+    assert n_c == n_s == (b * nb, b * nb)
+    assert cover[:nb] == [0.0] * nb and min(cover[nb:2 * nb]) > 0.2
+    for a, c in ((hint_c, hint_s), (final_c, final_s)):
+        assert (a.tsdf_weights > 0).sum().item() > 5000
+        assert torch.equal(a.tsdf_values.view(torch.int16), c.tsdf_values.view(torch.int16))
+        assert torch.equal(a.tsdf_weights.view(torch.int16), c.tsdf_weights.view(torch.int16))
