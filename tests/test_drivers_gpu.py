@@ -289,7 +289,10 @@ def test_revisit_flow_and_fused_second_pass_hints_on_one_gpu(tmp_path):
         assert torch.equal(torch.isnan(hint), torch.isnan(w_hint))
         assert torch.equal(hint[mask_b], w_hint[w_mask])
         assert (weights - w_weights).abs().max().item() < 2e-6
-        assert float(weights[~mask_b].abs().max()) == 0.0 and float(weights.max()) > 0.5  # no 0.025 cut, zero outside the render
+        assert float(weights[~mask_b].abs().max()) == 0.0 and float(weights.max()) > 0.0  # zero outside the render
+        # no 0.025 cut (test_offline_two_pass.py:354-356 has it commented out): rendered pixels keep their hint however
+        # small the sampled weight is
+        assert bool((mask_b & (weights < 0.025)).any()) or float(weights[mask_b].min()) >= 0.025
     # without the transform (= the two-pass second pass) the same equality holds
     cur, _ = load(0)
     st = between(hint_fuser)
