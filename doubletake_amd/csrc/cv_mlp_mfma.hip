@@ -73,9 +73,11 @@ struct ViewData {
   float z, sx, sy, sz, ang;
 };
 
+// (rx, ry, rz) = un-normalised current ray, rinv = 1 / its norm: the cosine below needs the unit ray only inside one dot
+// product, so the three normalised components are not kept (two registers less across the plane loop)
 __device__ __forceinline__ void issue_view(ViewData& v, cfloat_ptr vp,
                                            const float* __restrict__ src_view, float X, float Y, float Z,
-                                           float crx, float cry, float crz, int h, int w, float inv_w,
+                                           float rx, float ry, float rz, float rinv, int h, int w, float inv_w,
                                            float inv_h, int half) {
 #ifndef DT_MABL
 #define DT_MABL 0
@@ -110,7 +112,7 @@ __device__ __forceinline__ void issue_view(ViewData& v, cfloat_ptr vp,
   v.sx = sx * inv;
   v.sy = sy * inv;
   v.sz = sz * inv;
-  v.ang = crx * v.sx + cry * v.sy + crz * v.sz;
+  v.ang = (rx * v.sx + ry * v.sy + rz * v.sz) * rinv;
 }
 
 // hint MLP [3,12,12,1] evaluated from LDS.  Both lane halves of a wave hold the same pixel, so the 12 hidden
@@ -165,7 +167,6 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   float* lds_w1 = lds;
   float* lds_w2 = lds + n_dyn;
   float* lds_tail = lds_w2 + kW2Floats;
-  float* lds_stage = lds_tail + kTailFloats + kHintFloats + (threadIdx.x >> 6) * kStageFloats;
 
   // ---- stage the weights once per workgroup ------------------------------------------------
   {
@@ -202,8 +203,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, pl = lane & 31;
   const size_t hw = (size_t)h * w;
-  const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
+  // wave-uniform floats computed on the VALU (division): move them to SGPRs instead of holding a VGPR each
+  const float inv_w = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (float)w)));
+  const float inv_h = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (float)h)));
   const int lane_off = (half * 32 + pl) * 4;  // float offset of this lane inside a step block
+  float* lds_stage = lds_tail + kTailFloats + kHintFloats + wave * kStageFloats;  // (wave-uniform: stays in SGPRs)
   const long waves_total = (long)gridDim.x * NWAVES;
   const float b3 = lds_tail[256];
   const bool stage_ok = (D % 8 == 0);  // float4 alignment of the staged NHWC stores
@@ -218,25 +222,40 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   const int nblk = gridDim.x;
   const int lbid = (nblk % 8 == 0) ? (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   const long wid = (long)lbid * NWAVES + wave;
-  long u = wid * a.total_units / waves_total;
-  const long u_end = (wid + 1) * a.total_units / waves_total;
-  while (u < u_end) {
-    // integer division runs on the VALU, which makes its results "divergent" to the compiler and
-    // turns every per-view parameter read below into a waited vector load; readfirstlane restores
-    // wave-uniformity so they become scalar loads (SGPR operands, scalar cache).
+  // The span [u, u_end) is decomposed into (batch, tile, first plane) ONCE; the task loop then steps through it with
+  // integer compares only.  (Divisions inside the loop made the compiler hoist their reciprocal constants -- wave-uniform
+  // VALU results, i.e. VGPRs -- out of the loop and carry them, spilled, through every plane loop.)  Integer division runs
+  // on the VALU, which also makes its results "divergent" to the compiler; readfirstlane restores wave-uniformity so that
+  // the per-view parameter reads below are scalar loads (SGPR operands, scalar cache).
+  int remaining, d0, tile, b;
+  {
+    const long u = wid * a.total_units / waves_total;
+    const long u_end = (wid + 1) * a.total_units / waves_total;
     const long tile_global = u / D;
-    const int d0 = __builtin_amdgcn_readfirstlane((int)(u - tile_global * D));
-    const int d1 = __builtin_amdgcn_readfirstlane((int)min((long)D, d0 + (u_end - u)));
-    const int tile = __builtin_amdgcn_readfirstlane((int)(tile_global % a.num_tiles));
-    const int b = __builtin_amdgcn_readfirstlane((int)(tile_global / a.num_tiles));
-    u += d1 - d0;
+    d0 = __builtin_amdgcn_readfirstlane((int)(u - tile_global * D));
+    tile = __builtin_amdgcn_readfirstlane((int)(tile_global % a.num_tiles));
+    b = __builtin_amdgcn_readfirstlane((int)(tile_global / a.num_tiles));
+    remaining = __builtin_amdgcn_readfirstlane((int)(u_end - u));
+  }
+  for (; remaining > 0;) {
+    const int d1 = min(D, d0 + remaining);
     const cfloat_ptr p = as_const(a.params + (size_t)b * cv_params_floats(D, K));
     const float* src_b = a.src + (size_t)b * K * hw * kF;
 
-    const size_t pixi = (size_t)tile * 32 + pl;
-    const bool live = pixi < hw;
-    const size_t pc = live ? pixi : hw - 1;
-    const int y = (int)(pc / w), x = (int)(pc % w);
+    // Values that only the per-task prologue needs (the ten 64-bit addresses of this lane's w1pix fragments, the hint
+    // index scale, ...) are loop invariant, so the compiler hoisted them out of the TASK loop and kept them alive -- i.e.
+    // spilled: 23 VGPRs, 96 B of scratch per lane -- across the plane loop (round 2: 12.6 MB of scratch writes per launch).
+    // Deriving them from a per-task opaque copy of the lane id keeps them local to the prologue.
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
+    const int lane_off_t = ((lane_t >> 5) * 32 + (lane_t & 31)) * 4;
+    const unsigned pixi = (unsigned)tile * 32u + (unsigned)(lane_t & 31);
+    const bool live = pixi < (unsigned)hw;
+    const unsigned pc = live ? pixi : (unsigned)hw - 1u;
+    // (32-bit division by an opaque copy of w: its reciprocal is recomputed per task instead of living in a VGPR)
+    unsigned w_t = (unsigned)w;
+    asm volatile("" : "+s"(w_t));
+    const int y = (int)(pc / w_t), x = (int)(pc - (unsigned)y * w_t);
 
     // ---- per-pixel, plane-independent part ------------------------------------------------
     float cur8[8];
@@ -244,8 +263,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
     for (int j = 0; j < 8; ++j) cur8[j] = a.cur[((size_t)b * kF + half * 8 + j) * hw + pc];
     float rx, ry, rz;
     pixel_ray(p + kCvInvK, x, y, rx, ry, rz);
-    float crx = rx, cry = ry, crz = rz;
-    normalize3(crx, cry, crz);
+    // F.normalize: r / max(|r|, 1e-12)
+    const float rinv = 1.0f / fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
 
     f32x16 accp[4];
 #pragma unroll
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
 #pragma unroll
       for (int r = 0; r < 16; ++r) accp[i][r] = 0.f;
     {
-      const float4* wp = reinterpret_cast<const float4*>(a.w1pix + lane_off);
+      const float4* wp = reinterpret_cast<const float4*>(a.w1pix + lane_off_t);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const float4 a4 = wp[s * (kStepFloats / 4)];
@@ -261,12 +280,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
       }
       {
         const float4 a4 = wp[8 * (kStepFloats / 4)];
-        const float bv = half ? cry : crx;
+        const float bv = (half ? ry : rx) * rinv;
         DT_MFMA4(accp, a4, bv);
       }
       {
         const float4 a4 = wp[9 * (kStepFloats / 4)];
-        const float bv = half ? 1.0f : crz;
+        const float bv = half ? 1.0f : rz * rinv;
         DT_MFMA4(accp, a4, bv);
       }
       for (int k = 0; k < K; ++k) {
@@ -284,7 +303,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
     bool hmask = false;
     float hdepth = 0.f, hweight = 0.f;
     if (HINT) {
-      const int sy = nearest_src(y, a.hint_h, h), sx = nearest_src(x, a.hint_w2, w);
+      // (opaque copies: the two float scale factors of nearest_src are wave-uniform VALU results that would otherwise
+      // be hoisted out of the task loop and occupy / spill two VGPRs for the whole kernel)
+      int hh = a.hint_h, hw2 = a.hint_w2;
+      asm volatile("" : "+s"(hh), "+s"(hw2));
+      const int sy = nearest_src(y, hh, h), sx = nearest_src(x, hw2, w);
       const size_t hi = ((size_t)b * a.hint_h + sy) * a.hint_w2 + sx;
       hmask = a.hint_m[hi] != 0.f;
       hdepth = a.hint_d[hi];
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
     ViewData v;
     {
       const float depth = p[kCvPlanes + d0];
-      issue_view(v, p + cv_view_off(D, 0), src_b, depth * rx, depth * ry, depth * rz, crx, cry, crz, h, w, inv_w,
+      issue_view(v, p + cv_view_off(D, 0), src_b, depth * rx, depth * ry, depth * rz, rx, ry, rz, rinv, h, w, inv_w,
                  inv_h, half);
     }
     for (int d = d0; d < d1; ++d) {
@@ -328,8 +351,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
           }
           nd = min(nd, d1 - 1);
           const float ndepth = p[kCvPlanes + nd];
-          issue_view(v, p + cv_view_off(D, nk), src_b + (size_t)nk * hw * kF, ndepth * rx, ndepth * ry, ndepth * rz, crx,
-                     cry, crz, h, w, inv_w, inv_h, half);
+          issue_view(v, p + cv_view_off(D, nk), src_b + (size_t)nk * hw * kF, ndepth * rx, ndepth * ry, ndepth * rz, rx,
+                     ry, rz, rinv, h, w, inv_w, inv_h, half);
         }
         float dotp = 0.f;
 #pragma unroll
@@ -442,24 +465,36 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         if (!(DT_MABL & 2)) s = hint_mlp_eval_lds(lds_tail + kTailFloats, s, hint, hweight, half);
         else s += hint * hweight;
       }
+      // Store addresses are rebuilt from an opaque copy of the lane id at every store: hoisted out of the plane loop they
+      // were three 64-bit per-lane bases that lived (spilled) across the whole loop.  Uniform base + 32-bit lane offset.
       if (!a.out_nhwc) {
-        if (live && half == 0) a.vol[((size_t)b * D + d) * hw + pixi] = s;
+        int ls = lane;
+        asm volatile("" : "+v"(ls));
+        const unsigned px2 = (unsigned)tile * 32u + (unsigned)(ls & 31);
+        float* plane_base = a.vol + ((size_t)b * D + d) * hw;
+        if (px2 < (unsigned)hw && ls < 32) plane_base[px2] = s;
       } else if (!stage_ok) {
-        if (live && half == 0) a.vol[((size_t)b * hw + pixi) * D + d] = s;
+        int ls = lane;
+        asm volatile("" : "+v"(ls));
+        const unsigned px2 = (unsigned)tile * 32u + (unsigned)(ls & 31);
+        float* img_base = a.vol + (size_t)b * hw * D + d;
+        if (px2 < (unsigned)hw && ls < 32) img_base[(size_t)px2 * D] = s;
       } else {
         // NHWC volume: a lane-per-pixel store writes 4 bytes every D*4 bytes (11x write amplification
         // at the memory controller).  Park the scores of up to 8 consecutive planes in LDS and write
         // them as one float4 per lane, i.e. 32 contiguous bytes per pixel.
-        if (half == 0) lds_stage[pl * 8 + (d & 7)] = s;
+        int ls = lane;
+        asm volatile("" : "+v"(ls));
+        if (ls < 32) lds_stage[ls * 8 + (d & 7)] = s;
         if ((d & 7) == 7 || d == d1 - 1) {
           __builtin_amdgcn_wave_barrier();
           const int cbase = d & ~7;
           const int lo = max(d0, cbase) - cbase, hi = d - cbase;  // valid planes of this chunk: [lo, hi]
-          const int spx = lane >> 1, q = (lane & 1) * 4;
+          const int spx = ls >> 1, q = (ls & 1) * 4;
           const float4 v4 = *reinterpret_cast<const float4*>(lds_stage + spx * 8 + q);
-          const size_t spix = (size_t)tile * 32 + spx;
-          if (spix < hw) {
-            float* dst = a.vol + ((size_t)b * hw + spix) * D + cbase + q;
+          const unsigned spix = (unsigned)tile * 32u + (unsigned)spx;
+          if (spix < (unsigned)hw) {
+            float* dst = a.vol + (size_t)b * hw * D + cbase + ((size_t)spix * D + q);
             if (lo <= q && hi >= q + 3) {
               *reinterpret_cast<float4*>(dst) = v4;
             } else {
@@ -471,6 +506,16 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
           }
           __builtin_amdgcn_wave_barrier();
         }
+      }
+    }
+    // next task of the span: the following planes of the same tile, else plane 0 of the next tile / batch element
+    remaining -= d1 - d0;
+    d0 = d1;
+    if (d0 == D) {
+      d0 = 0;
+      if (++tile == a.num_tiles) {
+        tile = 0;
+        ++b;
       }
     }
   }
