@@ -249,6 +249,10 @@ def wait_ready(token, device):
         return
     import torch
 
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture nothing may look at an outside event; utils/graphs.py warms the caches up (and
+        # synchronises) before it captures, so the producer has long finished
+        return
     if ev.query():
         token[0] = None
         return

@@ -19,6 +19,8 @@ from ..modules import conv_ops as ops
 from ..modules.cost_volume import CostVolumeManager, FeatureMeshHintVolumeManager, FeatureVolumeManager
 from ..modules.networks import CVEncoder, DepthDecoderPP, ResnetMatchingEncoder
 from ..modules.networks_fast import SkipDecoderRegression
+from ..utils import graphs as _graphs
+from ..utils.graphs import GraphedCallable
 
 #: channel widths of the timm image encoders the reference uses (doubletake_model.py:121-130)
 ENCODER_WIDTHS = {"resnet18d": [64, 64, 128, 256, 512], "efficientnet": [24, 48, 64, 160, 256]}
@@ -44,13 +46,22 @@ class MatchingFeatureCache:
         return len(self._store)
 
     def get(self, fid):
+        """Entry for frame ``fid``; if it was produced on another stream (``prefetch_matching_feats``) the current
+        stream is made to wait for it first."""
         self._store.move_to_end(fid)
         self.hits += 1
-        return self._store[fid]
+        feat, ready = self._store[fid]
+        if ready is not None:
+            from .. import _abi
 
-    def put(self, fid, feat):
+            _abi.wait_ready(ready, feat.device)
+            if ready[0] is not None:  # still in flight on the producer stream: keep the allocator from recycling it early
+                feat.record_stream(torch.cuda.current_stream(feat.device))
+        return feat
+
+    def put(self, fid, feat, ready=None):
         self.misses += 1
-        self._store[fid] = feat
+        self._store[fid] = (feat, ready)
         self._store.move_to_end(fid)
         while len(self._store) > self.capacity:
             self._store.popitem(last=False)
@@ -166,8 +177,7 @@ class _HotPathDepthModel(nn.Module):
             flat_ids = [(scans[i], fid) for i, row in enumerate(ids) for fid in row]
             cache = self.matching_feature_cache
             # entries are only valid for the weights (and the image size) they were computed with
-            token = (tuple((p.data_ptr(), p._version) for p in self.matching_model.parameters()), tuple(flat.shape[1:]),
-                     str(flat.device))
+            token = self._cache_token(flat.shape[1:], flat.device)
             if cache.token != token:
                 cache.clear()
                 cache.token = token
@@ -177,7 +187,7 @@ class _HotPathDepthModel(nn.Module):
                 first.setdefault(flat_ids[j], j)
             todo = sorted(first.values())
             if todo:
-                new = self.matching_model(flat[todo])
+                new = self._encode(flat[todo])
                 for row, j in enumerate(todo):
                     cache.put(flat_ids[j], new[row])
             feats = torch.stack([cache.get(fid) for fid in flat_ids], dim=0)
@@ -188,11 +198,108 @@ class _HotPathDepthModel(nn.Module):
         feats = feats.view(b, m, *feats.shape[1:])
         return feats[:, 0], feats[:, 1:].contiguous()
 
+    def _cache_token(self, image_shape_chw, device):
+        return (tuple((p.data_ptr(), p._version) for p in self.matching_model.parameters()), tuple(image_shape_chw), str(device))
+
+    @torch.no_grad()
+    def prefetch_matching_feats(self, image_n3hw, frame_ids, scan_ids=None, stream=None):
+        """Encode keyframes AHEAD of the frame that needs them, on a side stream, into the feature cache.
+
+        In the incremental mode frame t cannot start before frame t-1's TSDF update (hint), but its matching features
+        depend on the image alone: encoded on a second HIP stream while frame t-1's latency-bound conv stack leaves most
+        of the chip idle, the 0.40 ms of the matching encoder disappear from the per-frame critical path
+        (``loops.run_incremental_scan(..., lookahead=...)``).  ``compute_matching_feats(..., cur_ids=, src_ids=)`` finds
+        the entries and orders its stream behind the encoder through the entry's event.  Frames already cached are skipped.
+        Returns the number of frames encoded."""
+        if self.matching_model is None:
+            raise RuntimeError("this model was built without a matching encoder")
+        from .. import _abi
+
+        dev = image_n3hw.device
+        n = image_n3hw.shape[0]
+        scans = [scan_ids] * n if isinstance(scan_ids, str) or scan_ids is None else list(scan_ids)
+        keys = [(scans[i], frame_ids[i]) for i in range(n)]
+        cache = self.matching_feature_cache
+        token = self._cache_token(image_n3hw.shape[1:], dev)
+        if cache.token != token:
+            cache.clear()
+            cache.token = token
+        first = {}
+        for j, key in enumerate(keys):
+            if key not in cache:
+                first.setdefault(key, j)
+        todo = sorted(first.values())
+        if not todo:
+            return 0
+        if stream is None:
+            stream = getattr(self, "_lookahead_stream", None)
+            if stream is None or stream.device != dev:
+                stream = self._lookahead_stream = torch.cuda.Stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        stream.wait_stream(cur)  # the images (and the weights) are ready on the caller's stream
+        with torch.cuda.stream(stream):
+            new = self._encode(image_n3hw[todo])
+            ready = _abi.record_ready(dev)
+        image_n3hw.record_stream(stream)
+        for row, j in enumerate(todo):
+            cache.put(keys[j], new[row], ready)
+        return len(todo)
+
+    # ---- hipGraph replay (opt-in) ----------------------------------------------------------------------------------
+    _HINT_KEYS = ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")
+
+    def enable_hip_graphs(self, on=True):
+        """Replay ``forward_from_features`` (and the single-image matching-encoder pass of the feature cache) from captured
+        hipGraphs instead of launching ~50 kernels from Python per keyframe (utils/graphs.py).  For fixed-shape loops --
+        above all the incremental mode, whose per-frame host time otherwise exceeds the GPU time.  The returned tensors
+        are then STATIC buffers, overwritten by the next call: consume or clone them first (the per-scan loops of
+        ``doubletake_amd.loops`` do).  Weights may change between calls (the graphs are keyed on their versions)."""
+        def between(_i):
+            hook = self.__dict__.pop("after_volume", None)
+            if hook is not None:
+                hook()
+
+        self._graphed_forward = GraphedCallable(self._forward_from_features_eager, between=between) if on else None
+        self._graphed_encoder = GraphedCallable(lambda img: self.matching_model(img)) if on and self.matching_model is not None else None
+        return self
+
+    def _weights_token(self):
+        return tuple(p._version for m in (self.cost_volume, self.cost_volume_net, self.depth_decoder) for p in m.parameters())
+
+    def _encode(self, images_n3hw):
+        """Matching encoder pass; single images replay a captured graph when graphs are on (the incremental loop encodes
+        exactly one new keyframe per frame)."""
+        g = getattr(self, "_graphed_encoder", None)
+        if g is not None and images_n3hw.shape[0] == 1:
+            token = tuple(p._version for p in self.matching_model.parameters())
+            if getattr(self, "_encoder_token", token) != token:
+                g.reset()
+            self._encoder_token = token
+            return g(images_n3hw).clone()  # (the cache keeps the features: they must not alias the graph's static output)
+        return self.matching_model(images_n3hw)
+
     @torch.no_grad()
     def forward_from_features(self, cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
                               cur_cam_T_src_cam, src_K, cur_invK, cv_depth_hint_dict=None, return_mask=False):
         """cur_feats: list of 5 image-prior maps (strides 2..32); matching feats at stride 4.
         Returns the reference's output dict (doubletake_model.py:410-423)."""
+        g = getattr(self, "_graphed_forward", None)
+        if g is None:
+            return self._forward_from_features_eager(cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
+                                                     cur_cam_T_src_cam, src_K, cur_invK, cv_depth_hint_dict, return_mask)
+        token = self._weights_token()
+        if getattr(self, "_forward_token", token) != token:
+            g.reset()  # packed weights are baked into the captured launches
+        self._forward_token = token
+        hint = None
+        if cv_depth_hint_dict is not None and isinstance(self.cost_volume, FeatureMeshHintVolumeManager):
+            hint = {k: cv_depth_hint_dict[k] for k in self._HINT_KEYS}  # (the drivers pass the whole cur_data dict)
+        return dict(g(list(cur_feats), matching_cur_feats, matching_src_feats, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K,
+                      cur_invK, hint, bool(return_mask)))
+
+    @torch.no_grad()
+    def _forward_from_features_eager(self, cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
+                                     cur_cam_T_src_cam, src_K, cur_invK, cv_depth_hint_dict=None, return_mask=False):
         dev = matching_cur_feats.device
         key = (str(dev), self.min_matching_depth, self.max_matching_depth)
         if getattr(self, "_depth_range_key", None) != key:  # device-resident constants, built once
@@ -206,6 +313,13 @@ class _HotPathDepthModel(nn.Module):
         if isinstance(self.cost_volume, FeatureMeshHintVolumeManager):  # the other managers take no hints
             kw["cv_depth_hint_dict"] = cv_depth_hint_dict
         cost_volume, lowest_cost, _, overall_mask = self.cost_volume(**kw)
+        _graphs.cut()  # (graph mode: the replay is split here so that the hook below can run between the two halves)
+        hook = None if torch.cuda.is_current_stream_capturing() else self.__dict__.pop("after_volume", None)
+        if hook is not None:
+            # one-shot: work for the caller to enqueue on ANOTHER stream behind the volume kernel (which fills every CU
+            # and all of its LDS) and beside the conv stack that follows (latency-bound, most of the chip idle):
+            # loops.matching_lookahead encodes the next frame's keyframe here
+            hook()
         cv_feats = self.cost_volume_net(cost_volume, cur_feats[self.matching_scale:])
         feats = list(cur_feats[: self.matching_scale]) + cv_feats
         if isinstance(self.depth_decoder, SkipDecoderRegression):
@@ -234,8 +348,14 @@ class _HotPathDepthModel(nn.Module):
         src_cam_T_cur_cam = src_data["cam_T_world_b44"] @ cur_data["world_T_cam_b44"].unsqueeze(1)
         cur_cam_T_src_cam = cur_data["cam_T_world_b44"].unsqueeze(1) @ src_data["world_T_cam_b44"]
         cur_feats = self.encoder(cur_data["image_b3hw"])
+        ids = {}
+        if getattr(self, "use_feature_cache", False) and "frame_id_string" in cur_data and "frame_id_string" in src_data:
+            # opt-in (model.use_feature_cache = True): keyframes are encoded once per scan and kept in HBM; the drivers'
+            # batches carry the ids (datasets ... pass_frame_id=True, test_incremental.py:150)
+            ids = dict(cur_ids=list(cur_data["frame_id_string"]), src_ids=[list(v) for v in src_data["frame_id_string"]],
+                       scan_ids=cur_data.get("scan_id_string"))
         m_cur, m_src = self.compute_matching_feats(cur_data["image_b3hw"], src_data["image_b3hw"],
-                                                   unbatched_matching_encoder_forward)  # (ids: opt-in, see above)
+                                                   unbatched_matching_encoder_forward, **ids)
         return self.forward_from_features(cur_feats, m_cur, m_src, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K,
                                           cur_invK, cur_data, return_mask=return_mask)
 

@@ -98,8 +98,24 @@ def _depth_for_fusion(outputs, size, mask_pred_depth=False, per_view_mask=True):
 
 
 @torch.no_grad()
+def matching_lookahead(model):
+    """``lookahead`` callable for run_incremental_scan: encodes the NEXT frame's new keyframe image into the model's HBM
+    feature cache on a side stream (DepthModelCVHint.prefetch_matching_feats) while the current frame is still running.
+    Needs ``model.use_feature_cache = True`` and batches that carry ``frame_id_string`` (pass_frame_id=True)."""
+    model.use_feature_cache = True
+
+    def run(cur_data, src_data):
+        model.prefetch_matching_feats(cur_data["image_b3hw"], list(cur_data["frame_id_string"]),
+                                      scan_ids=cur_data.get("scan_id_string"))
+
+    # the loop hands the call to the model, which issues it right behind the current frame's volume kernel: the encoder
+    # then runs beside the conv stack instead of delaying the volume kernel (which needs every CU's LDS to itself)
+    run.after_volume_of = model
+    return run
+
+
 def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fused_hint=True, mask_pred_depth=False,
-                         on_frame=None, timer: FrameTimer | None = None):
+                         on_frame=None, timer: FrameTimer | None = None, lookahead=None):
     """One scan of the incremental (online) mode; batch size 1 (reference test_incremental.py:25).
 
     batches: iterable of (cur_data, src_data); cur_data carries K_s0_b44 / invK_s0_b44 / cam_T_world_b44 /
@@ -107,11 +123,25 @@ def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fu
     depth_hint_mask_b1hw, depth_hint_mask_b_b1hw, sampled_weights_b1hw) are written into cur_data here.
     fused_hint: marching-cubes soup -> raster -> one back-project/sample/threshold kernel (4 launches) instead of the
     reference-shaped sequence over a merged mesh.  timer: a FrameTimer that receives hint_time / model_time per frame
-    (test_incremental.py:205,256-258,274-288).  Returns the number of frames fused."""
+    (test_incremental.py:205,256-258,274-288).  lookahead: callable(next_cur_data, next_src_data) run before the model of
+    the current frame -- work of frame t+1 that does not depend on frame t's result (``matching_lookahead``: its matching
+    features) and can fill the chip beside frame t's latency-bound kernels.  Returns the number of frames fused."""
     H2, W2 = render_hw
     renderer = None if fused_hint else MeshDepthRenderer(H2, W2)
     n = 0
-    for i, (cur_data, src_data) in enumerate(batches):
+
+    def with_next(it):
+        it = iter(it)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        for nxt in it:
+            yield cur, nxt
+            cur = nxt
+        yield cur, None
+
+    for i, ((cur_data, src_data), nxt) in enumerate(with_next(batches) if lookahead is not None else ((b, None) for b in batches)):
         if cur_data["cam_T_world_b44"].shape[0] != 1:
             raise ValueError("the incremental mode needs batch size 1 (frame t depends on the TSDF after frame t-1)")
         if i > 0:
@@ -128,6 +158,12 @@ def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fu
             empty_hint(cur_data, torch.zeros(1, 1, H2, W2, device=ref.device, dtype=torch.float32))
             if timer is not None:
                 timer.skip("hint_time")
+        if lookahead is not None and nxt is not None:
+            owner = getattr(lookahead, "after_volume_of", None)
+            if owner is not None:
+                owner.after_volume = (lambda nb=nxt: lookahead(*nb))
+            else:
+                lookahead(*nxt)
         if timer is not None:
             timer.start("model_time")
         outputs = model_fn(cur_data, src_data)

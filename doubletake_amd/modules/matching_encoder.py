@@ -159,13 +159,24 @@ def maxpool(x, k, stride, pad):
     return out
 
 
+def _blur_taps(blur: BlurPool):
+    """The 16 filter taps as a host array, read back ONCE per filter version (the kernels take them by value).  Reading
+    them on every call cost two device synchronisations per encoder pass -- and cannot be captured into a hipGraph."""
+    filt = blur.filt
+    key = (filt.data_ptr(), filt._version, str(filt.device))
+    hit = blur.__dict__.get("_dt_taps")
+    if hit is None or hit[0] != key:
+        if not bool((filt == filt[:1]).all()):
+            raise NotImplementedError("per-channel blur filters")
+        hit = (key, (C.c_float * 16)(*[float(v) for v in filt[0, 0].reshape(-1).tolist()]))
+        blur.__dict__["_dt_taps"] = hit
+    return hit[1]
+
+
 def blurpool(x, blur: BlurPool):
     L = _abi.lib()
     n, c, h, w = x.shape
-    filt = blur.filt
-    if not bool((filt == filt[:1]).all()):
-        raise NotImplementedError("per-channel blur filters")
-    f16 = (C.c_float * 16)(*[float(v) for v in filt[0, 0].reshape(-1).tolist()])
+    f16 = _blur_taps(blur)
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     out = ops.empty_nhwc(n, c, ho, wo, x.device)
     _abi.check(L.dt_blurpool4_s2_f32(_abi.ptr(x), _abi.ptr(out), f16, n, h, w, c, _abi.current_stream(x.device)),
@@ -177,10 +188,7 @@ def maxblur(x, blur: BlurPool):
     """MaxPool2d(2, stride 1) + BlurPool(4, stride 2) in one kernel."""
     L = _abi.lib()
     n, c, h, w = x.shape
-    filt = blur.filt
-    if not bool((filt == filt[:1]).all()):
-        raise NotImplementedError("per-channel blur filters")
-    f16 = (C.c_float * 16)(*[float(v) for v in filt[0, 0].reshape(-1).tolist()])
+    f16 = _blur_taps(blur)
     ho, wo = (h - 2) // 2 + 1, (w - 2) // 2 + 1
     out = ops.empty_nhwc(n, c, ho, wo, x.device)
     _abi.check(L.dt_maxblur_f32(_abi.ptr(x), _abi.ptr(out), f16, n, h, w, c, _abi.current_stream(x.device)),

@@ -1,0 +1,139 @@
+"""hipGraph replay of a fixed-shape call: capture once, replay with one host call.
+
+The hot path at batch 1 is a chain of ~50 short kernels per keyframe; launched eagerly from Python the HOST needs about
+1 ms per frame for them (ctypes call + tensor bookkeeping per launch), and the per-scan loops add more.  In the incremental
+mode -- where no second frame can hide it -- that made the loop host-bound (2.5 ms/frame of Python against 2.1 ms of GPU
+work, scripts/time_incremental.py).  A captured graph is replayed with a single hipGraphLaunch.
+
+``GraphedCallable(fn)`` wraps a function of tensors (positional / keyword arguments, nested in lists, tuples and dicts;
+non-tensor arguments are part of the signature).  For every distinct signature (shapes, dtypes, devices, constants) it
+  1. copies the arguments into static buffers it owns,
+  2. runs ``fn`` twice on a side stream (weight packs, per-stream library scratch, allocator pools),
+  3. captures ``fn`` into a graph (``torch.cuda.graph``: hipStreamBeginCapture on ROCm),
+and afterwards copies the new arguments into the static buffers (skipped when the caller hands over the static buffer
+itself) and replays.  The outputs are the SAME tensors on every call: consume (or clone) them before the next call with that
+signature.  One replay at a time per signature (the graph owns its intermediates and the library scratch of its capture
+stream).  No CPU fallback: capture needs a ROCm GPU."""
+from __future__ import annotations
+
+import torch
+
+
+def _flatten(obj, out):
+    """Tensors of a nested structure in a fixed order; returns a hashable skeleton describing everything else."""
+    if isinstance(obj, torch.Tensor):
+        out.append(obj)
+        return ("T", tuple(obj.shape), str(obj.dtype), str(obj.device), tuple(obj.stride()))
+    if isinstance(obj, (list, tuple)):
+        return (type(obj).__name__,) + tuple(_flatten(o, out) for o in obj)
+    if isinstance(obj, dict):
+        return ("dict",) + tuple((k, _flatten(obj[k], out)) for k in sorted(obj, key=str))
+    return ("C", obj if isinstance(obj, (int, float, str, bool, type(None))) else id(obj))
+
+
+def _rebuild(obj, tensors):
+    """The same structure with its tensors replaced, in _flatten order, by the next items of the iterator ``tensors``."""
+    if isinstance(obj, torch.Tensor):
+        return next(tensors)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_rebuild(o, tensors) for o in obj)
+    if isinstance(obj, dict):
+        rebuilt = {k: _rebuild(obj[k], tensors) for k in sorted(obj, key=str)}
+        return {k: rebuilt[k] for k in obj}
+    return obj
+
+
+_CAPTURING = None  # the GraphedCallable whose capture is in progress on this thread (cut() talks to it)
+
+
+def cut():
+    """Called by the wrapped function at a point where the replay should be split in two graphs, so that the owner can
+    enqueue other work (on another stream) between them -- ``GraphedCallable(fn, between=...)``.  A no-op outside a capture."""
+    if _CAPTURING is not None:
+        _CAPTURING._cut()
+
+
+class GraphedCallable:
+    def __init__(self, fn, warmup=2, between=None):
+        """between(i): called during replay after graph segment i (segments are separated by ``cut()`` calls in fn)."""
+        self.fn = fn
+        self.warmup = max(2, int(warmup))
+        self.between = between
+        self._entries = {}
+        self.captures = 0
+        self.replays = 0
+        self._segments = None
+        self._pool = None
+
+    def _cut(self):
+        self._segments[-1].capture_end()
+        g = torch.cuda.CUDAGraph()
+        self._segments.append(g)
+        g.capture_begin(pool=self._pool)
+
+    def _capture(self, args, kwargs, tensors):
+        dev = tensors[0].device
+        static = [t.detach().clone(memory_format=torch.preserve_format) for t in tensors]
+        s_args, s_kwargs = _rebuild((args, kwargs), iter(static))
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self.fn(*s_args, **s_kwargs)
+                # the second pass finds every weight-pack cache entry complete (their ready events have fired), so nothing
+                # in the captured pass has to look at an event recorded outside the capture
+                side.synchronize()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        # capture ON the warm-up stream: the library keeps its cross-workgroup reduction scratch per (device, stream) and
+        # must not allocate while a stream is capturing
+        global _CAPTURING
+        self._pool = torch.cuda.graph_pool_handle()
+        self._segments = [torch.cuda.CUDAGraph()]
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        _CAPTURING = self
+        try:
+            with torch.cuda.stream(side):
+                self._segments[0].capture_begin(pool=self._pool)
+                try:
+                    out = self.fn(*s_args, **s_kwargs)
+                finally:
+                    self._segments[-1].capture_end()
+        finally:
+            _CAPTURING = None
+        torch.cuda.current_stream(dev).wait_stream(side)
+        segments, self._segments = self._segments, None
+        self.captures += 1
+        return dict(graphs=segments, static=static, out=out)
+
+    def __call__(self, *args, **kwargs):
+        tensors = []
+        sig = _flatten((args, kwargs), tensors)
+        if not tensors or not tensors[0].is_cuda:
+            raise RuntimeError("GraphedCallable needs ROCm GPU tensors (no CPU fallback)")
+        ent = self._entries.get(sig)
+        if ent is None:
+            ent = self._entries[sig] = self._capture(args, kwargs, tensors)
+        for dst, src in zip(ent["static"], tensors):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        last = len(ent["graphs"]) - 1
+        for i, g in enumerate(ent["graphs"]):
+            g.replay()
+            if i < last and self.between is not None:
+                self.between(i)
+        self.replays += 1
+        return ent["out"]
+
+    def static_inputs(self, *args, **kwargs):
+        """The static input buffers (same nesting as the arguments) of the signature these arguments have -- capturing it
+        first if needed.  A producer that writes straight into them saves the per-call copies."""
+        tensors = []
+        sig = _flatten((args, kwargs), tensors)
+        ent = self._entries.get(sig)
+        if ent is None:
+            ent = self._entries[sig] = self._capture(args, kwargs, tensors)
+        return _rebuild((args, kwargs), iter(ent["static"]))
+
+    def reset(self):
+        self._entries.clear()

@@ -305,3 +305,51 @@ def test_revisit_flow_and_fused_second_pass_hints_on_one_gpu(tmp_path):
     doc = timer.write_scores(str(tmp_path / "scores.json"), "revisit", extra={"abs_diff": 0.1})
     back = formats.read_scores_json(str(tmp_path / "scores.json"))
     assert list(back["scores"]) == ["abs_diff", "hint_time", "model_time"] and back["scores"]["model_time"] == doc["scores"]["model_time"]
+
+
+def test_hip_graph_replay_equals_eager_launches():
+    """model.enable_hip_graphs(): forward_from_features and the single-image matching-encoder pass replayed from captured
+    hipGraphs give bit-identical outputs to eager launches, frame after frame with changing inputs; a weight update
+    invalidates the captured graphs; the feature-cache lookahead on a side stream feeds the same features."""
+    import gpu_util as gu
+    from doubletake_amd.utils.rendering_utils import empty_hint
+
+    dev = gu.dev()
+    H, W, k, D, b = 128, 160, 3, 16, 1
+    model = _model(H, W, k, D, dev)
+    cams = _cams(4, H // 2, W // 2)
+    frames = []
+    for f in range(4):
+        cur, src = _batch(f, b, k, H, W, dev, cams)
+        empty_hint(cur, torch.zeros(b, 1, H // 2, W // 2, device=dev))
+        cur["depth_hint_b1hw"] = torch.full_like(cur["depth_hint_b1hw"], 1.0 + 0.1 * f)   # hints that differ per frame
+        cur["depth_hint_mask_b1hw"] = torch.ones_like(cur["depth_hint_mask_b1hw"])
+        cur["sampled_weights_b1hw"] = torch.full_like(cur["sampled_weights_b1hw"], 0.3)
+        cur["frame_id_string"] = [f"{10 + f:06d}"]
+        src["frame_id_string"] = [[f"{10 + f - 1 - i:06d}"] for i in range(k)]
+        frames.append((cur, src))
+    keys = [f"depth_pred_s{i}_b1hw" for i in range(4)] + ["lowest_cost_bhw", "overall_mask_bhw"]
+    eager = [{kk: v.clone() for kk, v in model("test", c, s, return_mask=True).items() if kk in keys} for c, s in frames]
+    model.enable_hip_graphs(True)
+    for rep in range(2):
+        for (c, s), want in zip(frames, eager):
+            out = model("test", c, s, return_mask=True)
+            for kk in keys:
+                assert torch.equal(out[kk], want[kk]), (rep, kk)
+    assert model._graphed_forward.captures == 1 and model._graphed_forward.replays == 8
+    # weights change -> the graphs are rebuilt, results follow the new weights
+    with torch.no_grad():
+        model.depth_decoder.out4[4].bias.add_(0.25)
+    out = model("test", *frames[0], return_mask=True)
+    assert torch.allclose(out["log_depth_pred_s0_b1hw"], torch.log(eager[0]["depth_pred_s0_b1hw"]) + 0.25, atol=1e-5)
+    assert model._graphed_forward.captures == 2 and model._graphed_forward.replays == 9   # (reset + one new capture)
+    # feature cache + lookahead: the next frame's keyframe encoded on a side stream by the graphed encoder
+    model.use_feature_cache = True
+    model.matching_feature_cache.clear()
+    ref_feats = model.matching_model(frames[1][0]["image_b3hw"])
+    assert model.prefetch_matching_feats(frames[1][0]["image_b3hw"], frames[1][0]["frame_id_string"]) == 1
+    assert model.prefetch_matching_feats(frames[1][0]["image_b3hw"], frames[1][0]["frame_id_string"]) == 0   # already cached
+    m_cur, _ = model.compute_matching_feats(frames[1][0]["image_b3hw"], frames[1][1]["image_b3hw"], cur_ids=frames[1][0]["frame_id_string"],
+                                            src_ids=frames[1][1]["frame_id_string"])
+    torch.cuda.synchronize()
+    assert torch.equal(m_cur, ref_feats)
