@@ -302,8 +302,8 @@ def main():
                     help="run consecutive keyframes on this many HIP streams (frames are independent in this workload; the "
                          "TSDF integrations stay in frame order)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the model part of the step from 3 hipGraphs (cut around the dominant kernel) instead of "
-                         "launching eagerly; measured no faster -- the eager step is already GPU-bound (DESIGN.md 4.3)")
+                    help="replay the model part of the step from hipGraphs (model.enable_hip_graphs; one graph set per stream) "
+                         "instead of ~50 eager launches per keyframe")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still create the RCCL process group and run the per-step all_gather "
                          "(checks the N>1 code path on a single GPU)")
@@ -377,49 +377,31 @@ def main():
         return model.forward_from_features(pyr_t, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"],
                                            t["src_Ks"], t["cur_invK"], hint, return_mask=True)
 
-    # ---- hipGraph capture of the model part of a step, cut into three graphs at the dominant kernel so
-    # that HIP events recorded between the replays bracket exactly cv_mlp_mfma_kernel -------------------
+    # ---- --graph: the model part of a step replayed from hipGraphs (model.enable_hip_graphs: segments cut around the
+    # dominant kernel, so the HIP events still bracket exactly cv_mlp_mfma_kernel).  One graph set per stream ("lane"): a
+    # shallow copy of the model shares the parameters and owns its captured graphs and static buffers. -------------------
     graphs = None
+    lanes = None
     if args.graph:
-        try:
-            # allocator / weight-pack / per-stream conv scratch warm-up outside capture, ON the capture stream (the library
-            # keeps its cross-workgroup reduction scratch per stream and cannot allocate while the stream is capturing)
-            cap_stream = torch.cuda.Stream(device)
-            cap_stream.wait_stream(torch.cuda.current_stream(device))
-            with torch.cuda.stream(cap_stream):
-                for _ in range(3):
-                    model_step()
-            torch.cuda.synchronize(device)
-            pool = torch.cuda.graph_pool_handle()
-            gs = [torch.cuda.CUDAGraph() for _ in range(3)]
-            state = {"i": 0}
+        import copy
 
-            def cut(tag):
-                gs[state["i"]].capture_end()
-                state["i"] += 1
-                gs[state["i"]].capture_begin(pool=pool)
+        lanes = []
+        for i in range(max(1, args.streams)):
+            m = model if i == 0 else copy.copy(model)
+            m.enable_hip_graphs(True)
+            (sa, _) = m._graphed_forward.static_inputs(list(pyr_t), t["cur_feats"], t["src_feats"], t["src_extrinsics"],
+                                                       t["src_poses"], t["src_Ks"], t["cur_invK"], dict(hint), True)
+            lanes.append((m, sa))  # calling with the static buffers themselves skips the per-call input copies
+        torch.cuda.synchronize(device)
+        graphs = True
 
-            cvmod.FeatureVolumeManager._event_hook = staticmethod(cut)
-            cap_stream.wait_stream(torch.cuda.current_stream(device))
-            with torch.cuda.stream(cap_stream):
-                gs[0].capture_begin(pool=pool)
-                static_out = model_step()
-                gs[state["i"]].capture_end()
-            torch.cuda.current_stream(device).wait_stream(cap_stream)
-            cvmod.FeatureVolumeManager._event_hook = None
-            assert state["i"] == 2
-            graphs = (gs, static_out)
-        except Exception as e:  # capture unsupported: run eagerly and say so
-            cvmod.FeatureVolumeManager._event_hook = None
-            graphs = None
-            print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
-            torch.cuda.synchronize(device)
+    def model_step_lane(i):
+        m, sa = lanes[i % len(lanes)]
+        return m.forward_from_features(sa[0], sa[1], sa[2], sa[3], sa[4], sa[5], sa[6], sa[7], return_mask=True)
 
     # --streams S: consecutive keyframes are independent in this workload (offline keyframe batches: hints and cameras
     # are inputs), so frame i runs on HIP stream i % S and the latency-bound conv stacks of neighbouring frames overlap;
     # only the TSDF integrations are chained (frame order) through events.
-    if args.graph:
-        args.streams = 1  # the graph experiment replays from one stream
     streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if args.streams > 1 else None
     fuse_done = {"ev": None}
 
@@ -432,14 +414,9 @@ def main():
 
     def step_on_current(frame_idx, timed=False):
         if graphs is not None:
-            gs, out = graphs
-            gs[0].replay()
+            out = model_step_lane(frame_idx)  # (the event hook fires between the graph segments)
             if timed:
-                hook("mlp_begin")
-            gs[1].replay()
-            if timed:
-                hook("mlp_end")
-            gs[2].replay()
+                hook("model_end")
         else:
             out = model_step()
             if timed:
@@ -470,8 +447,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
-    if graphs is None:
-        cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
+    cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, timed=True)
@@ -516,26 +492,25 @@ def main():
     mends = [e for tag, e, _ in events if tag == "model_end"]
     kern_ms = float(np.mean([b.elapsed_time(e) for b, e in zip(begins, ends)])) if begins else float("nan")
     conv_ms = float(np.mean([b.elapsed_time(e) for b, e in zip(ends, mends)])) if mends else float("nan")
-    # launches of one step: library kernels between the hooks of the last timed step (host-side counter)
-    n_conv_launches = n_model_launches = None
-    if mends:
-        cb = [c for tag, _, c in events if tag == "mlp_begin"][-1]
-        ce = [c for tag, _, c in events if tag == "mlp_end"][-1]
-        cm = [c for tag, _, c in events if tag == "model_end"][-1]
-        n_conv_launches = cm - ce
-    # direct-convolution-equivalent FLOPs of the conv stack + heads of one step (one extra, untimed step with the op-level
-    # accounting switched on)
-    conv_flops = None
-    if graphs is None:
-        from doubletake_amd.modules import conv_ops as _ops
+    # direct-convolution-equivalent FLOPs and kernel launches of one step: one extra, untimed, EAGER step with the op-level
+    # accounting switched on and the library's launch counter read at the hooks
+    conv_flops = n_conv_launches = n_model_launches = None
+    from doubletake_amd.modules import conv_ops as _ops
 
-        _ops.ACCOUNT = {"flops": 0.0, "calls": 0}
-        c0 = int(L.dt_kernel_launch_count())
-        model_step()
-        n_model_launches = int(L.dt_kernel_launch_count()) - c0
-        torch.cuda.synchronize(device)
-        conv_flops = _ops.ACCOUNT["flops"]
-        _ops.ACCOUNT = None
+    if graphs is not None:
+        model.enable_hip_graphs(False)
+    counts = {}
+    cvmod.FeatureVolumeManager._event_hook = staticmethod(lambda tag: counts.__setitem__(tag, int(L.dt_kernel_launch_count())))
+    _ops.ACCOUNT = {"flops": 0.0, "calls": 0}
+    c0 = int(L.dt_kernel_launch_count())
+    model_step()
+    c1 = int(L.dt_kernel_launch_count())
+    torch.cuda.synchronize(device)
+    cvmod.FeatureVolumeManager._event_hook = None
+    conv_flops = _ops.ACCOUNT["flops"]
+    _ops.ACCOUNT = None
+    n_model_launches = c1 - c0
+    n_conv_launches = c1 - counts.get("mlp_end", c1)
 
     if rank == 0:
         h, w = CFG["image_h"] // 4, CFG["image_w"] // 4
@@ -578,7 +553,8 @@ def main():
                 "matching_resolution": [h, w],
                 "frames_per_step_per_gpu": CFG["batch"],
                 "streams": args.streams,
-                "launch": "3 hipGraphs per step (cut around the dominant kernel) + eager TSDF exchange/integrate" if graphs is not None else "eager",
+                "launch": "hipGraph replay of the model step (4 segments, cut around the dominant kernel), one graph set per stream; "
+                          "eager TSDF exchange/integrate" if graphs is not None else "eager",
                 "parallelism": f"keyframe-shard x{world}" + ("" if args.no_fuse else " + all_gather(depth,K,pose) + replica TSDF integrate"),
             },
             "roofline": {

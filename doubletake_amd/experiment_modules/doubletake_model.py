@@ -254,10 +254,17 @@ class _HotPathDepthModel(nn.Module):
         above all the incremental mode, whose per-frame host time otherwise exceeds the GPU time.  The returned tensors
         are then STATIC buffers, overwritten by the next call: consume or clone them first (the per-scan loops of
         ``doubletake_amd.loops`` do).  Weights may change between calls (the graphs are keyed on their versions)."""
-        def between(_i):
-            hook = self.__dict__.pop("after_volume", None)
-            if hook is not None:
-                hook()
+        def between(tag):
+            if tag == "after_volume":
+                hook = self.__dict__.pop("after_volume", None)
+                if hook is not None:
+                    hook()
+            else:  # "mlp_begin" / "mlp_end": the event hook bench.py brackets the dominant kernel with
+                from ..modules.cost_volume import FeatureVolumeManager
+
+                hook = FeatureVolumeManager._event_hook
+                if hook is not None:
+                    hook(tag)
 
         self._graphed_forward = GraphedCallable(self._forward_from_features_eager, between=between) if on else None
         self._graphed_encoder = GraphedCallable(lambda img: self.matching_model(img)) if on and self.matching_model is not None else None
@@ -313,7 +320,7 @@ class _HotPathDepthModel(nn.Module):
         if isinstance(self.cost_volume, FeatureMeshHintVolumeManager):  # the other managers take no hints
             kw["cv_depth_hint_dict"] = cv_depth_hint_dict
         cost_volume, lowest_cost, _, overall_mask = self.cost_volume(**kw)
-        _graphs.cut()  # (graph mode: the replay is split here so that the hook below can run between the two halves)
+        _graphs.cut("after_volume")  # (graph mode: the replay is split here so that the hook below runs between the halves)
         hook = None if torch.cuda.is_current_stream_capturing() else self.__dict__.pop("after_volume", None)
         if hook is not None:
             # one-shot: work for the caller to enqueue on ANOTHER stream behind the volume kernel (which fills every CU

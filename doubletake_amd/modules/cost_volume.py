@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 
 from .. import _abi
+from ..utils import graphs as _graphs
 from . import mlp_pack
 from .networks import MLP
 
@@ -360,7 +361,8 @@ class FeatureVolumeManager(CostVolumeManager):
         else:
             vol = torch.empty(b, D, h, w, device=dev, dtype=torch.float32)
         hook = FeatureVolumeManager._event_hook
-        if hook is not None:
+        _graphs.cut("mlp_begin")  # (hipGraph capture: segment boundary, see utils/graphs.py; a no-op otherwise)
+        if hook is not None and not torch.cuda.is_current_stream_capturing():
             hook("mlp_begin")
         if _impl == "mfma" and self.precision == "split16":
             _abi.check(L.dt_cv_mlp_hint_split_f32(
@@ -380,7 +382,8 @@ class FeatureVolumeManager(CostVolumeManager):
                 "dt_cv_mlp_hint_simple_f32")
         else:
             raise ValueError(_impl)
-        if hook is not None:
+        _graphs.cut("mlp_end")
+        if hook is not None and not torch.cuda.is_current_stream_capturing():
             hook("mlp_end")
         low = self._lowest(L, stream, vol, params, nhwc, dims)
         mask = None

@@ -46,16 +46,17 @@ def _rebuild(obj, tensors):
 _CAPTURING = None  # the GraphedCallable whose capture is in progress on this thread (cut() talks to it)
 
 
-def cut():
+def cut(tag=None):
     """Called by the wrapped function at a point where the replay should be split in two graphs, so that the owner can
-    enqueue other work (on another stream) between them -- ``GraphedCallable(fn, between=...)``.  A no-op outside a capture."""
+    enqueue other work between them -- an event, or a launch on another stream: ``GraphedCallable(fn, between=...)``
+    receives ``tag`` after the segment that ends here.  A no-op outside a capture."""
     if _CAPTURING is not None:
-        _CAPTURING._cut()
+        _CAPTURING._cut(tag)
 
 
 class GraphedCallable:
     def __init__(self, fn, warmup=2, between=None):
-        """between(i): called during replay after graph segment i (segments are separated by ``cut()`` calls in fn)."""
+        """between(tag): called during replay after every graph segment that a ``cut(tag)`` call in fn ended."""
         self.fn = fn
         self.warmup = max(2, int(warmup))
         self.between = between
@@ -63,9 +64,11 @@ class GraphedCallable:
         self.captures = 0
         self.replays = 0
         self._segments = None
+        self._tags = None
         self._pool = None
 
-    def _cut(self):
+    def _cut(self, tag):
+        self._tags.append(tag)
         self._segments[-1].capture_end()
         g = torch.cuda.CUDAGraph()
         self._segments.append(g)
@@ -89,6 +92,7 @@ class GraphedCallable:
         global _CAPTURING
         self._pool = torch.cuda.graph_pool_handle()
         self._segments = [torch.cuda.CUDAGraph()]
+        self._tags = []
         side.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
         _CAPTURING = self
@@ -104,7 +108,7 @@ class GraphedCallable:
         torch.cuda.current_stream(dev).wait_stream(side)
         segments, self._segments = self._segments, None
         self.captures += 1
-        return dict(graphs=segments, static=static, out=out)
+        return dict(graphs=segments, tags=list(self._tags), static=static, out=out)
 
     def __call__(self, *args, **kwargs):
         tensors = []
@@ -117,11 +121,11 @@ class GraphedCallable:
         for dst, src in zip(ent["static"], tensors):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
-        last = len(ent["graphs"]) - 1
+        tags = ent["tags"]
         for i, g in enumerate(ent["graphs"]):
             g.replay()
-            if i < last and self.between is not None:
-                self.between(i)
+            if i < len(tags) and self.between is not None:
+                self.between(tags[i])
         self.replays += 1
         return ent["out"]
 
