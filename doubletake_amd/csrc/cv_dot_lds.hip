@@ -192,11 +192,16 @@ __global__ __launch_bounds__(64 * kDotWaves, DT_DOT_OCC) void cv_dot_lds_kernel(
       for (int j = 0; j < kDotMaxGroup; ++j) pd[j] = p[kCvPlanes + min(d0 + j, D - 1)];
 
       for (int k = kb; k < min(kb + 8, K); ++k) {
-        float vp[12];
+        // q(depth) = P [depth r; 1] = depth (P3 r) + P[:,3]: the 3x3 part is applied to this lane's ray ONCE per view, a
+        // plane then costs three FMAs instead of a 3x4 matrix-vector product.  Staged and direct path share the expression.
+        float pa[3], pt[3];
         {
           cfloat_ptr vpc = p + cv_view_off(D, k);
 #pragma unroll
-          for (int i = 0; i < 12; ++i) vp[i] = vpc[i];
+          for (int i = 0; i < 3; ++i) {
+            pa[i] = vpc[4 * i + 0] * rx + vpc[4 * i + 1] * ry + vpc[4 * i + 2] * rz;
+            pt[i] = vpc[4 * i + 3];
+          }
         }
         const float* base = src_bkhwc + ((size_t)b * K + k) * hw * C;
         int bx0 = 0, by0 = 0, bw = 0, bh = 0;
@@ -240,7 +245,14 @@ __global__ __launch_bounds__(64 * kDotWaves, DT_DOT_OCC) void cv_dot_lds_kernel(
 
         // ---- address phase of one plane: projection, taps, LDS offsets ------------------------------------------------
         auto prepare = [&](const float depth, DotSample& sm, const bool staged) {
-          const ViewProj q = project_view(vp, depth * rx, depth * ry, depth * rz);
+          ViewProj q;
+          {
+            const float qx = depth * pa[0] + pt[0], qy = depth * pa[1] + pt[1], qz = depth * pa[2] + pt[2];
+            q.z = qz + 1e-8f;
+            const float sc = (fabsf(qz) > 1e-8f) ? (1.0f / q.z) : 1.0f;  // Project3D (utils/geometry_utils.py:82-93)
+            q.u = qx * sc;
+            q.v = qy * sc;
+          }
           const Taps t = bilinear_taps(q.u, q.v, h, w, inv_w, inv_h);
           sm.w00 = t.w00; sm.w01 = t.w01; sm.w10 = t.w10; sm.w11 = t.w11;
           sm.z = q.z;
