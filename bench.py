@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--mlp-precision", choices=("fp32", "split16"), default="fp32",
                     help="arithmetic of the matching-MLP contractions in the volume kernel: exact fp32 MFMA (default, the headline) "
                          "or the opt-in split-precision mode (fp16 hi/lo operands on the fp16 matrix pipe, fp32 accumulation)")
+    ap.add_argument("--conv-precision", choices=("fp32", "split16"), default="fp32",
+                    help="arithmetic of the 3x3 stride-1 conv layers: exact fp32 MFMA (default, the headline) or the opt-in "
+                         "split-precision Winograd kernel (fp16 hi/lo products on the fp16 matrix pipe, fp32 accumulation)")
     ap.add_argument("--streams", type=int, default=2,
                     help="run consecutive keyframes on this many HIP streams (frames are independent in this workload; the "
                          "TSDF integrations stay in frame order)")
@@ -348,6 +351,9 @@ def main():
     inp, pyr, t, pyr_t = build_inputs(device, seed=1000 + rank)
     model = build_model(device)
     model.cost_volume.precision = args.mlp_precision
+    from doubletake_amd.modules import conv_ops as _conv_ops
+
+    _conv_ops.CONV_PRECISION = args.conv_precision
     hint = {n: t[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
     fuser = None
     if not args.no_fuse:
@@ -544,7 +550,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.mlp_precision == "fp32" else "f32 (opt-in: MLP products as split fp16 hi/lo pairs, f32 accumulate)",
+            "dtype": "f32" if (args.mlp_precision == "fp32" and args.conv_precision == "fp32") else
+                     "f32 (opt-in: " + " and ".join((["MLP"] if args.mlp_precision != "fp32" else []) +
+                                                     (["3x3 conv"] if args.conv_precision != "fp32" else [])) +
+                     " products as split fp16 hi/lo pairs, f32 accumulate)",
             "data": "synthetic",
             "config": {
                 "workload": "hot path (mesh-hint cost volume + CVEncoder + "

@@ -62,6 +62,10 @@ SIGNATURES = {
     "dt_conv_wino_pack_floats": (_L, [_I, _I]),
     "dt_conv_wino_pack_f32": (_I, [_P, _P, _I, _I, _P]),
     "dt_conv2d_wino_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dt_conv_wino_split_pack_halves": (_L, [_I, _I]),
+    "dt_conv_wino_split_pack_f16": (_I, [_P, _P, _I, _I, _P]),
+    "dt_conv2d_wino_split_supported": (_I, [C.POINTER(ConvDesc)]),
+    "dt_conv2d_wino_split_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "dt_conv2d_pair_f32": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "dt_conv2d_simple_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "dt_conv1x1_head_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
@@ -153,7 +157,7 @@ class _ForeignStream(C.c_void_p):
 
 
 #: entry points whose trailing void* is a data pointer, not a stream
-_NO_STREAM = frozenset()
+_NO_STREAM = frozenset({"dt_conv2d_wino_split_supported"})
 
 
 def _guarded(fn):

@@ -121,6 +121,34 @@ def packed_weight_wino(conv: nn.Conv2d, device):
     return packed
 
 
+def packed_weight_wino_split(conv: nn.Conv2d, device):
+    """Winograd-domain weights as fp16 hi/lo fragments for the opt-in split-precision kernel; cached per weight version."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(device))
+    hit = getattr(conv, "_dt_pack_wino_split", None)
+    if hit is not None and hit[0] == key:
+        _abi.wait_ready(hit[2], device)
+        return hit[1]
+    co, ci, k, k2 = w.shape
+    if (k, k2) != (3, 3) or conv.stride != (1, 1) or conv.groups != 1 or conv.dilation != (1, 1) or conv.padding != (1, 1):
+        raise NotImplementedError(f"Winograd path needs a 3x3 stride-1 pad-1 conv, got {conv}")
+    L = _abi.lib()
+    wd = w.detach().to(device=device, dtype=torch.float32).contiguous()
+    packed = torch.empty(int(L.dt_conv_wino_split_pack_halves(co, ci)), device=device, dtype=torch.int16)
+    _abi.check(L.dt_conv_wino_split_pack_f16(_abi.ptr(wd), _abi.ptr(packed), co, ci, _abi.current_stream(device)),
+               "dt_conv_wino_split_pack_f16")
+    conv._dt_pack_wino_split = (key, packed, _abi.record_ready(device))
+    return packed
+
+
+#: arithmetic of the Winograd-domain products of the 3x3 stride-1 layers: "fp32" (default, exact fp32 MFMA) or the opt-in
+#: "split16" (fp16 hi/lo operand pairs on the fp16 matrix pipe, fp32 accumulation; csrc/conv_wino_split.hip).  Layers the
+#: split kernel does not take (fewer than SPLIT_MIN_BLOCKS workgroups, a source that is not a multiple of 16 channels,
+#: stride 2, 1x1) stay on the fp32 kernels.  DT_CONV_PRECISION sets the initial value.
+CONV_PRECISION = _os.environ.get("DT_CONV_PRECISION", "fp32")
+SPLIT_MIN_BLOCKS = int(_os.environ.get("DT_CONV_SPLIT_MIN_BLOCKS", "128"))
+
+
 #: use the Winograd kernel for 3x3 stride-1 layers with at least this many 8x16-pixel x 32-channel workgroups
 #: (set by measurement, see DESIGN.md section 4.2: 96 = down to the 30x40 level, whose 96 blocks run as 2 workgroups each;
 #: 48 = the 15x20 level too measured slower); DT_CONV_WINO_MIN_BLOCKS overrides, 0 disables
@@ -191,11 +219,15 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
         # channel counts the 32-channel x 8-channel-group MFMA tiling cannot express (the reference's own
         # configurations never produce them): the general-shape kernel, same fused epilogue
         impl = "simple"
-    if impl == "mfma" and k == 3 and st == 1 and co % 32 == 0 and WINO_MIN_BLOCKS > 0:
-        wino_blocks = n * ((d.h_out + 7) // 8) * ((d.w_out + 15) // 16) * (co // 32)
-        if wino_blocks >= WINO_MIN_BLOCKS:
-            impl = "wino"
-    if impl == "wino":
+    wino_blocks = n * ((d.h_out + 7) // 8) * ((d.w_out + 15) // 16) * (co // 32) if (k == 3 and st == 1 and co % 32 == 0) else 0
+    if impl == "mfma" and wino_blocks > 0 and WINO_MIN_BLOCKS > 0 and wino_blocks >= WINO_MIN_BLOCKS:
+        impl = "wino"
+    if impl == "wino" and CONV_PRECISION == "split16" and wino_blocks >= SPLIT_MIN_BLOCKS \
+            and conv.padding_mode in ("zeros", "replicate") and L.dt_conv2d_wino_split_supported(C.byref(d)):
+        wp = packed_weight_wino_split(conv, dev)
+        _abi.check(L.dt_conv2d_wino_split_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wp), _abi.ptr(bias),
+                                              _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_wino_split_f32")
+    elif impl == "wino":
         wp = packed_weight_wino(conv, dev)
         _abi.check(L.dt_conv2d_wino_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wp), _abi.ptr(bias),
                                         _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_wino_f32")
@@ -256,6 +288,9 @@ def conv2d_pair(srcs, conv_a: nn.Conv2d, act_a, conv_b: nn.Conv2d, act_b):
     a_wino = False
     if sa == 1 and WINO_MIN_BLOCKS > 0:
         a_wino = da.n * ((da.h_out + 7) // 8) * ((da.w_out + 15) // 16) * (co_a // 32) >= WINO_MIN_BLOCKS
+    if a_wino and CONV_PRECISION == "split16":
+        # the split-precision Winograd kernel has no paired form: two launches
+        return conv2d(srcs, conv_a, act=act_a), conv2d(srcs, conv_b, act=act_b)
     if not a_wino:
         da.transposed = 1 if _want_transposed(L, da) else 0
     db.transposed = 1 if _want_transposed(L, db) else 0

@@ -189,6 +189,16 @@ int dt_conv_wino_pack_f32(const float* W_oihw, float* packed, int c_out, int c_i
 int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2,
                        const float* packed_w, const float* bias, const float* residual,
                        float* out, dt_stream_t s);
+/* OPT-IN split-precision Winograd variant (csrc/conv_wino_split.hip): same function as dt_conv2d_wino_f32, the Winograd-domain
+ * products as fp16 hi/lo pairs on v_mfma_f32_32x32x16_f16 with fp32 accumulation (x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo,
+ * 2^-22 relative).  Not the default path.  Needs every source to be a multiple of 16 channels (..._supported returns 1).
+ * packed_w: dt_conv_wino_split_pack_halves 16-bit words made by dt_conv_wino_split_pack_f16 from the OIHW weight. */
+int64_t dt_conv_wino_split_pack_halves(int c_out, int c_in);
+int dt_conv_wino_split_pack_f16(const float* W_oihw, uint16_t* packed, int c_out, int c_in, dt_stream_t s);
+int dt_conv2d_wino_split_supported(const dt_conv_desc* d);
+int dt_conv2d_wino_split_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2,
+                             const uint16_t* packed_w, const float* bias, const float* residual,
+                             float* out, dt_stream_t s);
 /* conv1 and the shortcut ("downsample") conv of a BasicBlock (modules/layers.py:77-94) in ONE launch: both read the
  * same (virtually concatenated) sources.  A: 3x3, stride 1 or 2, weights packed by dt_conv_wino_pack_f32 when a_wino != 0
  * (stride 1 only) else by dt_conv_pack_f32.  B: 1x1 stride 1 (with a stride-1 A) or 3x3 stride 2 (with a stride-2 A),

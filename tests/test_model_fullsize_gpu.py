@@ -193,3 +193,28 @@ def test_fullsize_fixture_catches_a_swapped_skip_connection():
         _check(g, name, "log_depth_pred_s0_b1hw", out["log_depth_pred_s0_b1hw"].cpu().numpy(), 2e-4)
     with pytest.raises(AssertionError):
         _check(g, name, "depth_pred_s0_b1hw", torch.exp(out["log_depth_pred_s0_b1hw"]).cpu().numpy(), 1e-3)
+
+
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg2_full", "cfg3_full_b8"])
+def test_whole_model_split_precision_conv_stack_within_depth_tolerance(name):
+    """Opt-in split-precision conv stack (conv_ops.CONV_PRECISION = "split16": the 3x3 stride-1 layers on
+    csrc/conv_wino_split.hip, fp16 hi/lo products with fp32 accumulation) inside the whole model, against the same reference
+    full-size checksums and the same tolerances as the exact-fp32 path (depth 1e-3, log depth 2e-4, UNet++ nodes 3e-4)."""
+    import gpu_util as gu
+    from doubletake_amd.modules import conv_ops as ops
+
+    g = load_golden("model_fullsize_checksums.npz")
+    model, inp, t, pyr = build_case(name)
+    prev = ops.CONV_PRECISION
+    ops.CONV_PRECISION = "split16"
+    try:
+        before = int(ops._abi.lib().dt_kernel_launch_count())
+        out = model.forward_from_features(pyr, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"], t["src_Ks"],
+                                          t["cur_invK"], gu.hint_dict(t), return_mask=True)
+        torch.cuda.synchronize()
+        assert int(ops._abi.lib().dt_kernel_launch_count()) > before
+    finally:
+        ops.CONV_PRECISION = prev
+    for i in range(4):
+        _check(g, name, f"depth_pred_s{i}_b1hw", out[f"depth_pred_s{i}_b1hw"].cpu().numpy(), 1e-3)
+        _check(g, name, f"log_depth_pred_s{i}_b1hw", out[f"log_depth_pred_s{i}_b1hw"].cpu().numpy(), 2e-4)

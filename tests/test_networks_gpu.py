@@ -423,3 +423,41 @@ def test_conv_random_shapes_vs_direct(c):
     assert (got - want).abs().max().item() < 4e-6 * max(want.abs().max().item(), 5.0)
     assert got.abs().max().item() > 0.05
     assert torch.equal(ops.conv2d(srcs, conv, act=c["act"], residual=res), got)
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64, 120, 160, 1), (2, 128, 64, 60, 80, 2), (1, 64, 32, 37, 53, 1), (1, 96, 64, 24, 40, 3)])
+def test_split_precision_winograd_conv_matches_the_fp32_kernels(shape):
+    """Opt-in split-precision Winograd conv (csrc/conv_wino_split.hip: fp16 hi/lo operand pairs on the fp16 matrix pipe,
+    fp32 accumulation) against the exact-fp32 Winograd kernel and the direct general-shape kernel on the same inputs:
+    multi-source concat with a nearest x2 upsampled source, bias, residual, LeakyReLU / ELU, ragged extents, batch 2."""
+    import gpu_util as gu
+    import torch.nn as nn
+
+    from doubletake_amd.modules import conv_ops as ops
+
+    n, cin, cout, h, w, nsrc = shape
+    dev = gu.dev()
+    conv = nn.Conv2d(cin, cout, 3, padding=1).to(dev)
+    gu.set_formula_weights(conv, 31 + cin)
+    cs = [cin] if nsrc == 1 else ([cin // 2, cin // 2] if nsrc == 2 else [cin // 3, cin // 3, cin // 3])
+    up_first = nsrc >= 2 and h % 2 == 0 and w % 2 == 0
+    srcs = []
+    for i, c in enumerate(cs):
+        hh, ww = (h // 2, w // 2) if (i == 0 and up_first) else (h, w)
+        x = ops.as_nhwc(torch.from_numpy(syn.hash_normalish((n, c, hh, ww), 50 + i)).to(dev))
+        srcs.append((x, i == 0 and up_first))
+    res = ops.as_nhwc(torch.from_numpy(syn.hash_normalish((n, cout, h, w), 77)).to(dev))
+    for act in (ops.ACT_LRELU02, ops.ACT_ELU):
+        want = ops.conv2d(srcs, conv, act=act, residual=res, impl="wino")
+        simple = ops.conv2d(srcs, conv, act=act, residual=res, impl="simple")
+        prev = ops.CONV_PRECISION, ops.SPLIT_MIN_BLOCKS
+        ops.CONV_PRECISION, ops.SPLIT_MIN_BLOCKS = "split16", 1
+        try:
+            got = ops.conv2d(srcs, conv, act=act, residual=res, impl="wino")
+        finally:
+            ops.CONV_PRECISION, ops.SPLIT_MIN_BLOCKS = prev
+        torch.cuda.synchronize()
+        scale = max(float(simple.abs().max()), 1.0)
+        assert float((got - want).abs().max()) < 3e-6 * scale, (act, float((got - want).abs().max()))
+        assert float((got - simple).abs().max()) < 6e-6 * scale
+        assert float((want - simple).abs().max()) < 6e-6 * scale
