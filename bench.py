@@ -101,9 +101,9 @@ def cpu_baseline(inp, pyr, model, threads="8,all", batched=False):
     reference composes, in its loop-over-planes order) on the SAME frame the GPU steps process -- mesh-hint volume,
     lowest cost, CVEncoder, SkipDecoderRegression, exp -- timed on this box's host cores with torch.set_num_threads(8)
     (the survey container's count) and with every physical core.  Bounded to about 25 s of CPU
-    work: one whole frame first (warm-up, parity depths, cross-check), then the plane loop over every 4th plane (5 runs,
-    median; one run at the other thread counts) and the conv part (3 runs); the batched (Fast-manager) volume once on
-    request.  Returns (dict for the JSON line, depth maps)."""
+    work: one whole frame first (warm-up, parity depths, cross-check), then the plane loop over every 4th plane (3 runs,
+    median; one run at the other thread counts) and the conv part (3 runs); the batched (Fast-manager) volume once
+    (BASELINE.md section 3 asks for both variants; --no-cpu-batched skips it).  Returns (dict for the JSON line, depth maps)."""
     import torch
     from oracle import torch_cpu_ref as tref
 
@@ -142,7 +142,7 @@ def cpu_baseline(inp, pyr, model, threads="8,all", batched=False):
 
     # Bounded sample (about 25 s of CPU work instead of 95 s for full-frame repeats): ONE whole frame at 8 threads -- warm-up,
     # the depth maps of the parity check, and a cross-check of the estimate -- then the volume loop over every
-    # SAMPLE_STRIDE-th plane (all planes run the same ops on the same shapes) 5 times at 8 threads (median) and once with
+    # SAMPLE_STRIDE-th plane (all planes run the same ops on the same shapes) 3 times at 8 threads (median) and once with
     # every physical core, and the conv part (lowest cost, CVEncoder, decoder, exp) 3 times.  frame = stride x sample + rest.
     SAMPLE_STRIDE = 4
     sample_ids = list(range(0, CFG["planes"], SAMPLE_STRIDE))
@@ -154,7 +154,7 @@ def cpu_baseline(inp, pyr, model, threads="8,all", batched=False):
     rest_ts = sorted(rest(vol, planes)[0] for _ in range(3))
     rest_s = rest_ts[1]
     runs = {}
-    plan = [(8, 5)] + [(n, 1) for n in thread_counts if n != 8]
+    plan = [(8, 3)] + [(n, 1) for n in thread_counts if n != 8]
     for nt, n_timed in plan:
         torch.set_num_threads(nt)
         ts = sorted(volume(sample_ids)[0] for _ in range(n_timed))
@@ -293,7 +293,8 @@ def main():
                          "print the same one-line JSON without the cpu_baseline / dot-kernel side legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", default="8,all", help="thread counts of the cpu_baseline leg ('all' = physical cores)")
-    ap.add_argument("--cpu-batched", action="store_true", help="also time the batched (Fast-manager) CPU volume once")
+    ap.add_argument("--no-cpu-batched", dest="cpu_batched", action="store_false",
+                    help="skip the one timing of the batched (Fast-manager) CPU volume (BASELINE.md section 3 asks for both variants)")
     ap.add_argument("--no-fuse", action="store_true", help="skip the TSDF integration of the gathered frames")
     ap.add_argument("--mlp-precision", choices=("fp32", "split16"), default="fp32",
                     help="arithmetic of the matching-MLP contractions in the volume kernel: exact fp32 MFMA (default, the headline) "

@@ -145,6 +145,11 @@ __device__ __forceinline__ float hint_mlp_eval_lds(const float* hm, float s, flo
   return part + __shfl_xor(part, 32, 64) + hm[216];
 }
 
+// skip the feature MFMAs of (tile, plane, view) triples whose footprint misses the source image (A/B switch)
+#ifndef DT_MLP_SKIP_EMPTY
+#define DT_MLP_SKIP_EMPTY 1
+#endif
+
 #define DT_MFMA4(ACC, A4, BVAL)                                                   \
   do {                                                                            \
     ACC[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A4).x, (BVAL), ACC[0], 0, 0, 0); \
@@ -340,6 +345,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         f[6] = v.t00b.z * v.w00 + v.t01b.z * v.w01 + v.t10b.z * v.w10 + v.t11b.z * v.w11;
         f[7] = v.t00b.w * v.w00 + v.t01b.w * v.w01 + v.t10b.w * v.w10 + v.t11b.w * v.w11;
         const float vz = v.z, vang = v.ang, vsx = v.sx, vsy = v.sy, vsz = v.sz;
+        // No pixel of this 32-pixel tile sees the view at this plane (every bilinear weight of every lane is zero: the
+        // footprint lies outside the source image): the warped features are exactly 0 and their 32 MFMAs add exactly 0 --
+        // skip them (wave-uniform).  The metadata steps below still run (depth, angle and rays are defined regardless).
+        const bool tile_sees_view = DT_MLP_SKIP_EMPTY ? __builtin_amdgcn_ballot_w64((v.w00 != 0.f) | (v.w01 != 0.f) | (v.w10 != 0.f) |
+                                                                                   (v.w11 != 0.f)) != 0ull
+                                                      : true;
         {
           // branch-free: the loop body stays ONE basic block, so the scheduler can place the next
           // view's projection / address / gather instructions between this view's MFMAs.  The
@@ -361,10 +372,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         const float m = (vz > 0.f) ? 1.f : 0.f;
 
         const float4* wl = reinterpret_cast<const float4*>(lds_w1 + (size_t)k * kStepsPerView * kStepFloats + lane_off);
+        if (tile_sees_view) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const float4 a4 = wl[s * (kStepFloats / 4)];
-          DT_MFMA4(acc1, a4, f[s]);
+          for (int s = 0; s < 8; ++s) {
+            const float4 a4 = wl[s * (kStepFloats / 4)];
+            DT_MFMA4(acc1, a4, f[s]);
+          }
         }
         {
           const float4 a4 = wl[8 * (kStepFloats / 4)];
