@@ -42,8 +42,11 @@ def run(b, k, h, w, D, seed, impl, n=30):
 
 def main():
     once = "--once" in sys.argv
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None  # one shape per process (per-shape PMC passes)
     out = {}
     for name, (b, k, h, w, D, seed) in {"cfg2": (1, 7, 120, 160, 64, 1000), "cfg3_b8": (8, 7, 96, 128, 64, 303)}.items():
+        if only is not None and name != only:
+            continue
         ms, _ = run(b, k, h, w, D, seed, "lds", 3 if once else 30)
         out[name] = {"lds_ms": ms}
         if not once:
