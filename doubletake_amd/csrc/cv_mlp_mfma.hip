@@ -41,6 +41,7 @@ constexpr int kTailFloats = 260;   // b2r[128], w3r[128], b3, pad[3]
 constexpr int kHintFloats = 220;   // hint MLP (217 floats) staged in LDS behind the tail
 constexpr int kStageFloats = 256;  // per wave: 32 pixels x 8 planes of finished scores awaiting a 32-byte store
 constexpr int kMaxSrcMfma = 7;     // LDS budget: 12*K + 64 + ~1 KB <= 160 KB
+constexpr int kMaxSrcStream = 15;  // with the views beyond the seventh streamed from global memory (STREAM instantiation)
 
 __host__ __device__ inline int mlp_w1dyn_floats(int K) { return K * kStepsPerView * kStepFloats; }
 __host__ __device__ inline int mlp_w1pix_floats(int K) { return (kPixFixed + 2 * K) * kStepFloats; }
@@ -163,12 +164,17 @@ __device__ __forceinline__ float hint_mlp_eval_lds(const float* hm, float s, flo
 //             features (one accumulator chain) to fit the register budget.
 // A chain of dependent v_mfma_f32_32x32x2_f32 issues at ~1/4 of the pipe rate, so >= 4 independent
 // accumulators must be in flight per SIMD to keep the matrix pipe full.
-template <bool HINT, int NWAVES>
+// STREAM = false: K <= 7 source views, every view's layer-1 fragments resident in LDS (the reference default and every
+//                 released checkpoint; the tuned headline path -- its code is untouched by the other instantiation).
+// STREAM = true : 7 < K <= 15: the first seven views as above, the fragments of the further views are read from global
+//                 memory (L2) inside the view loop -- 12 KB per view and wave-pass, behind the 48 MFMAs of the view.
+template <bool HINT, int NWAVES, bool STREAM = false>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(const MlpArgs a) {
   constexpr int NT = NWAVES * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int K = a.K, D = a.D, h = a.h, w = a.w;
-  const int n_dyn = mlp_w1dyn_floats(K);
+  const int K_lds = STREAM ? min(K, kMaxSrcMfma) : K;  // views whose layer-1 weights live in LDS
+  const int n_dyn = mlp_w1dyn_floats(K_lds);
   float* lds_w1 = lds;
   float* lds_w2 = lds + n_dyn;
   float* lds_tail = lds_w2 + kW2Floats;
@@ -348,7 +354,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         // No pixel of this 32-pixel tile sees the view at this plane (every bilinear weight of every lane is zero: the
         // footprint lies outside the source image): the warped features are exactly 0 and their 32 MFMAs add exactly 0 --
         // skip them (wave-uniform).  The metadata steps below still run (depth, angle and rays are defined regardless).
-        const bool tile_sees_view = DT_MLP_SKIP_EMPTY ? __builtin_amdgcn_ballot_w64((v.w00 != 0.f) | (v.w01 != 0.f) | (v.w10 != 0.f) |
+        // (only in the hint instantiation -- DoubleTake's kernel: in the no-hint one the extra branch cost 15 spilled VGPRs)
+        const bool tile_sees_view = (DT_MLP_SKIP_EMPTY && HINT) ? __builtin_amdgcn_ballot_w64((v.w00 != 0.f) | (v.w01 != 0.f) | (v.w10 != 0.f) |
                                                                                    (v.w11 != 0.f)) != 0ull
                                                       : true;
         {
@@ -371,34 +378,44 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         const float dot = dotp + __shfl_xor(dotp, 32, 64);
         const float m = (vz > 0.f) ? 1.f : 0.f;
 
-        const float4* wl = reinterpret_cast<const float4*>(lds_w1 + (size_t)k * kStepsPerView * kStepFloats + lane_off);
-        if (tile_sees_view) {
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const float4 a4 = wl[s * (kStepFloats / 4)];
-            DT_MFMA4(acc1, a4, f[s]);
-          }
+        // the 12 K steps of view k against its layer-1 fragments (WL: LDS for resident views, global memory for streamed ones)
+#define DT_L1_VIEW(WL)                                                              \
+  do {                                                                              \
+    if (tile_sees_view) {                                                           \
+      _Pragma("unroll") for (int s = 0; s < 8; ++s) {                               \
+        const float4 a4 = (WL)[s * (kStepFloats / 4)];                              \
+        DT_MFMA4(acc1, a4, f[s]);                                                   \
+      }                                                                             \
+    }                                                                               \
+    {                                                                               \
+      const float4 a4 = (WL)[8 * (kStepFloats / 4)];                                \
+      const float bv = half ? vz : m;                                               \
+      DT_MFMA4(acc1, a4, bv);                                                       \
+    }                                                                               \
+    {                                                                               \
+      const float4 a4 = (WL)[9 * (kStepFloats / 4)];                                \
+      const float bv = half ? vang : dot * m;                                       \
+      DT_MFMA4(acc1, a4, bv);                                                       \
+    }                                                                               \
+    {                                                                               \
+      const float4 a4 = (WL)[10 * (kStepFloats / 4)];                               \
+      const float bv = half ? vsy : vsx;                                            \
+      DT_MFMA4(acc1, a4, bv);                                                       \
+    }                                                                               \
+    {                                                                               \
+      const float4 a4 = (WL)[11 * (kStepFloats / 4)];                               \
+      const float bv = half ? ((k == 0) ? depth : 0.f) : vsz;                       \
+      DT_MFMA4(acc1, a4, bv);                                                       \
+    }                                                                               \
+  } while (0)
+        if (!STREAM || k < K_lds) {
+          const float4* wl = reinterpret_cast<const float4*>(lds_w1 + (size_t)k * kStepsPerView * kStepFloats + lane_off);
+          DT_L1_VIEW(wl);
+        } else {
+          const float4* wg = reinterpret_cast<const float4*>(a.w1dyn + (size_t)k * kStepsPerView * kStepFloats + lane_off);
+          DT_L1_VIEW(wg);
         }
-        {
-          const float4 a4 = wl[8 * (kStepFloats / 4)];
-          const float bv = half ? vz : m;
-          DT_MFMA4(acc1, a4, bv);
-        }
-        {
-          const float4 a4 = wl[9 * (kStepFloats / 4)];
-          const float bv = half ? vang : dot * m;
-          DT_MFMA4(acc1, a4, bv);
-        }
-        {
-          const float4 a4 = wl[10 * (kStepFloats / 4)];
-          const float bv = half ? vsy : vsx;
-          DT_MFMA4(acc1, a4, bv);
-        }
-        {
-          const float4 a4 = wl[11 * (kStepFloats / 4)];
-          const float bv = half ? ((k == 0) ? depth : 0.f) : vsz;
-          DT_MFMA4(acc1, a4, bv);
-        }
+#undef DT_L1_VIEW
       }
 
       // ---- layer 1 activation (bias came in through the constant-1 input) ------------------
@@ -546,7 +563,7 @@ using namespace dt;
 extern "C" {
 
 int dt_cv_mlp_pack_floats(int num_src, int* w1dyn, int* w1pix, int* w2p, int* tail) {
-  DT_REQUIRE(num_src > 0 && num_src <= kMaxSrcMfma, "dt_cv_mlp_pack_floats: num_src=%d not in 1..%d", num_src, kMaxSrcMfma);
+  DT_REQUIRE(num_src > 0 && num_src <= kMaxSrcStream, "dt_cv_mlp_pack_floats: num_src=%d not in 1..%d", num_src, kMaxSrcStream);
   if (w1dyn) *w1dyn = mlp_w1dyn_floats(num_src);
   if (w1pix) *w1pix = mlp_w1pix_floats(num_src);
   if (w2p) *w2p = kW2Floats;
@@ -560,7 +577,7 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
                        int hint_w, float* volume, int out_nhwc, int batch, int num_src, int h, int w,
                        int num_planes, dt_stream_t s) {
   DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0, "dt_cv_mlp_hint_f32: bad extents");
-  DT_REQUIRE(num_src > 0 && num_src <= kMaxSrcMfma, "dt_cv_mlp_hint_f32: num_src=%d not in 1..%d", num_src, kMaxSrcMfma);
+  DT_REQUIRE(num_src > 0 && num_src <= kMaxSrcStream, "dt_cv_mlp_hint_f32: num_src=%d not in 1..%d", num_src, kMaxSrcStream);
   DT_REQUIRE(cur && src && params && w1dyn && w1pix && w2p && tail && volume, "dt_cv_mlp_hint_f32: null pointer");
   DT_REQUIRE(hint_mlp == nullptr || (depth_hint && hint_weights && hint_mask && hint_h > 0 && hint_w > 0),
              "dt_cv_mlp_hint_f32: hint MLP given without hint maps");
@@ -573,25 +590,28 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
   a.num_tiles = (int)((hw + 31) / 32);
   const int cus = num_cus();
   a.total_units = (long)batch * a.num_tiles * num_planes;
-  const int nw = g_mlp_waves;
-  const size_t lds_bytes =
-      (size_t)(mlp_w1dyn_floats(num_src) + kW2Floats + kTailFloats + kHintFloats + nw * kStageFloats) * sizeof(float);
+  const int nw = (num_src > kMaxSrcMfma) ? 4 : g_mlp_waves;  // streamed views: one wave per SIMD (register room for the loads in flight)
+  const bool stream = num_src > kMaxSrcMfma;  // more views than LDS holds: the further views' fragments come from L2
+  const size_t lds_bytes = (size_t)(mlp_w1dyn_floats(stream ? kMaxSrcMfma : num_src) + kW2Floats + kTailFloats + kHintFloats +
+                                    nw * kStageFloats) * sizeof(float);
   const long want = (a.total_units + nw - 1) / nw;  // at least one unit per wave
   const int blocks = (int)(want < cus ? want : cus);
-#define DT_LAUNCH_MLP(HINT_, NW_)                                                                                  \
+#define DT_LAUNCH_MLP(HINT_, NW_, ST_)                                                                             \
   do {                                                                                                             \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cv_mlp_mfma_kernel<HINT_, NW_>),               \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cv_mlp_mfma_kernel<HINT_, NW_, ST_>),          \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                \
     if (e != hipSuccess) {                                                                                         \
       (void)hipGetLastError();                                                                                     \
       return fail("dt_cv_mlp_hint_f32: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));          \
     }                                                                                                              \
-    DT_LAUNCH((cv_mlp_mfma_kernel<HINT_, NW_>), dim3(blocks), dim3(NW_ * 64), lds_bytes, to_stream(s), a); \
+    DT_LAUNCH((cv_mlp_mfma_kernel<HINT_, NW_, ST_>), dim3(blocks), dim3(NW_ * 64), lds_bytes, to_stream(s), a);      \
   } while (0)
-  if (hint_mlp) {
-    if (nw == 8) DT_LAUNCH_MLP(true, 8); else DT_LAUNCH_MLP(true, 4);
+  if (stream) {  // (the one-wave-per-SIMD variant only: spill free with the streamed fragments in flight)
+    if (hint_mlp) DT_LAUNCH_MLP(true, 4, true); else DT_LAUNCH_MLP(false, 4, true);
+  } else if (hint_mlp) {
+    if (nw == 8) DT_LAUNCH_MLP(true, 8, false); else DT_LAUNCH_MLP(true, 4, false);
   } else {
-    if (nw == 8) DT_LAUNCH_MLP(false, 8); else DT_LAUNCH_MLP(false, 4);
+    if (nw == 8) DT_LAUNCH_MLP(false, 8, false); else DT_LAUNCH_MLP(false, 4, false);
   }
 #undef DT_LAUNCH_MLP
   return check_launch("dt_cv_mlp_hint_f32");

@@ -259,7 +259,8 @@ class FeatureVolumeManager(CostVolumeManager):
     #: it to record HIP events on the launch stream (roofline timing)
     _event_hook = None
     #: source views the fused MFMA kernel handles (84 KB of layer-1 weights per 7 views stay in LDS)
-    MAX_FUSED_VIEWS = 7
+    MAX_FUSED_VIEWS = 15       # fused MFMA kernel: <= 7 views fully LDS-resident, 8..15 with the further views streamed from L2
+    MAX_SPLIT16_VIEWS = 7      # the opt-in split-precision kernel keeps every view resident
     _warned_views = False
     #: arithmetic of the fused MLP volume: "fp32" (default, exact fp32 MFMA) or "split16" (OPT-IN: fp16 hi/lo operands on
     #: the fp16 matrix pipe, fp32-class accuracy, ~4x less matrix time; csrc/cv_mlp_split.hip).  Set on an instance
@@ -300,7 +301,7 @@ class FeatureVolumeManager(CostVolumeManager):
             val = {n: torch.from_numpy(v).to(device) for n, v in packed.items()}
         raw = self._mlp_arrays(self.mlp)
         val["raw"] = [_f32c(a.to(device)) for a in raw]
-        if self.num_source_views <= self.MAX_FUSED_VIEWS and self.precision == "split16":
+        if self.num_source_views <= self.MAX_SPLIT16_VIEWS and self.precision == "split16":
             sp = mlp_pack.pack_mlp_split(*arrs, self.num_source_views)
             for n in ("w1dyn", "w1pix", "w2"):
                 val["sp_" + n] = torch.from_numpy(sp[n].view(np.int16).copy()).to(device)
@@ -333,8 +334,8 @@ class FeatureVolumeManager(CostVolumeManager):
             raise ValueError("matching features must have 16 channels")
         dev = cur.device
         if k > self.MAX_FUSED_VIEWS and _impl == "mfma":
-            # the fused MFMA kernel keeps the layer-1 weights of <= 7 views resident in LDS (the reference's default and
-            # every released checkpoint); more views run on the general kernel -- correct, but not the tuned path
+            # the fused MFMA kernel takes up to 15 source views (the reference's default is 7; the views beyond the seventh
+            # stream their layer-1 weights from L2); more run on the general kernel -- correct, but not the tuned path
             if not FeatureVolumeManager._warned_views:
                 import warnings
 
@@ -364,7 +365,7 @@ class FeatureVolumeManager(CostVolumeManager):
         _graphs.cut("mlp_begin")  # (hipGraph capture: segment boundary, see utils/graphs.py; a no-op otherwise)
         if hook is not None and not torch.cuda.is_current_stream_capturing():
             hook("mlp_begin")
-        if _impl == "mfma" and self.precision == "split16":
+        if _impl == "mfma" and self.precision == "split16" and k <= self.MAX_SPLIT16_VIEWS:
             _abi.check(L.dt_cv_mlp_hint_split_f32(
                 _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(pk["sp_w1dyn"]), _abi.ptr(pk["sp_w1pix"]),
                 _abi.ptr(pk["sp_w2"]), _abi.ptr(pk["tail"]), _abi.ptr(hint_ptr), _abi.ptr(hd), _abi.ptr(hw_),

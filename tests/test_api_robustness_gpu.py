@@ -55,22 +55,50 @@ def test_loud_failures():
         m(**{k_: (v.cpu() if torch.is_tensor(v) else v) for k_, v in args.items()}, cv_depth_hint_dict=hd)
     with pytest.raises(ValueError):
         m(**{**args, "cur_feats": args["cur_feats"][:, :, :-1]}, cv_depth_hint_dict=hd)
-    # more source views than the fused kernel keeps resident in LDS: the general HIP kernel takes over (with a warning)
+    # more source views than the fused kernel keeps resident in LDS (7): up to 15 the MFMA kernel streams the further views'
+    # layer-1 weights from L2 (round 3), beyond that the general HIP kernel takes over with a warning
     from oracle import cost_volume_ref as cref
 
-    k = 9
+    for k in (9, 12):
+        inp = syn.volume_inputs(1, k, 8, 12, 16, 5)
+        t9 = gu.to_dev(inp)
+        m9 = FeatureMeshHintVolumeManager(8, 12, num_depth_bins=6, num_source_views=k).to(gu.dev())
+        mw = gu.load_formula_mlp(m9.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 31)
+        hw9 = gu.load_formula_mlp(m9.hint_mlp, [3, 12, 12, 1], 32)
+        import warnings as _w
+
+        with _w.catch_warnings():
+            _w.simplefilter("error")  # no fallback warning: the fused kernel runs
+            vol9 = m9(**gu.volume_call_args(t9), cv_depth_hint_dict=gu.hint_dict(t9))[0]
+        simple9 = m9._forward_impl(**gu.volume_call_args(t9), cv_depth_hint_dict=gu.hint_dict(t9), depth_planes_bdhw=None,
+                                   return_mask=False, _impl="simple")[0]
+        want9, _, _ = cref.feature_volume(inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
+                                          inp["cur_invK"], inp["min_depth"], inp["max_depth"], 6, mw,
+                                          hint={n: inp[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")},
+                                          hint_mlp_weights=hw9)
+        assert np.abs(vol9.cpu().numpy() - want9).max() < 5e-5, k
+        assert np.abs(simple9.cpu().numpy() - want9).max() < 5e-5, k
+        # the no-hint manager through the same streamed instantiation
+        from doubletake_amd.modules.cost_volume import FeatureVolumeManager
+
+        f9 = FeatureVolumeManager(8, 12, num_depth_bins=6, num_source_views=k).to(gu.dev())
+        gu.load_formula_mlp(f9.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 31)
+        want_f, _, _ = cref.feature_volume(inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
+                                           inp["cur_invK"], inp["min_depth"], inp["max_depth"], 6, mw)
+        assert np.abs(f9(**gu.volume_call_args(t9))[0].cpu().numpy() - want_f).max() < 5e-5, k
+    k = 16
     inp = syn.volume_inputs(1, k, 8, 12, 16, 5)
-    t9 = gu.to_dev(inp)
-    m9 = FeatureMeshHintVolumeManager(8, 12, num_depth_bins=6, num_source_views=k).to(gu.dev())
-    mw = gu.load_formula_mlp(m9.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 31)
-    hw9 = gu.load_formula_mlp(m9.hint_mlp, [3, 12, 12, 1], 32)
+    t17 = gu.to_dev(inp)
+    m17 = FeatureMeshHintVolumeManager(8, 12, num_depth_bins=6, num_source_views=k).to(gu.dev())
+    mw = gu.load_formula_mlp(m17.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 31)
+    hw17 = gu.load_formula_mlp(m17.hint_mlp, [3, 12, 12, 1], 32)
     with pytest.warns(UserWarning, match="source views"):
-        vol9 = m9(**gu.volume_call_args(t9), cv_depth_hint_dict=gu.hint_dict(t9))[0]
-    want9, _, _ = cref.feature_volume(inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
-                                      inp["cur_invK"], inp["min_depth"], inp["max_depth"], 6, mw,
-                                      hint={n: inp[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")},
-                                      hint_mlp_weights=hw9)
-    assert np.abs(vol9.cpu().numpy() - want9).max() < 5e-5
+        vol17 = m17(**gu.volume_call_args(t17), cv_depth_hint_dict=gu.hint_dict(t17))[0]
+    want17, _, _ = cref.feature_volume(inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
+                                       inp["cur_invK"], inp["min_depth"], inp["max_depth"], 6, mw,
+                                       hint={n: inp[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")},
+                                       hint_mlp_weights=hw17)
+    assert np.abs(vol17.cpu().numpy() - want17).max() < 5e-5
     # conv primitive: channel counts the MFMA tiling cannot express run on the general-shape kernel (same result as torch)
     conv = torch.nn.Conv2d(12, 20, 3, padding=1).to(gu.dev())
     xin = torch.from_numpy(syn.hash_normalish((1, 12, 8, 8), 3)).to(gu.dev())
