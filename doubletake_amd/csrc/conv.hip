@@ -129,6 +129,9 @@ constexpr int conv_waves_per_eu(int threads) { return threads / 256 * DT_CONV_OC
 
 // -DDT_CONV_TIMING: wave 0 of every workgroup of the K-split kernels records s_memrealtime (100 MHz) at its phase
 // boundaries into the buffer whose address the host reads from the environment (scripts/conv_phase_timing.py).
+#ifndef DT_WINO_TIMING_WAVE
+#define DT_WINO_TIMING_WAVE 0
+#endif
 #ifdef DT_CONV_TIMING
 #define DT_STAMP(SLOT)                                                                              \
   do {                                                                                              \
@@ -757,6 +760,19 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
   // whose share is exhausted stages zeros against (re-read, harmless) weights
   const int g_stride = KSPLIT * kparts, g_base = part * KSPLIT;
   const int iters = (a.groups - g_base + g_stride - 1) / g_stride;
+#ifdef DT_CONV_TIMING
+  // phase accounting of ONE wave per workgroup (s_memrealtime, 10 ns ticks; reading a stamp drains lgkmcnt, i.e. it waits
+  // for this wave's outstanding LDS operations -- which is what the phases are meant to include)
+  unsigned long long tph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime(), tbegin = tlast;
+#define DTW_STAMP(K)                                                        \
+  do {                                                                      \
+    const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();       \
+    tph[K] += now_ - tlast;                                                 \
+    tlast = now_;                                                           \
+  } while (0)
+#else
+#define DTW_STAMP(K) do { } while (0)
+#endif
   if (g_base + ks < a.groups) DTW_PREFETCH(g_base + ks);
   for (int i = 0; i < iters; ++i) {
     const int g = g_base + ks + i * g_stride;
@@ -772,8 +788,14 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
     float4 wc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) wc[b] = w[b];
+#ifdef DT_CONV_TIMING
+    asm volatile("s_nop 0" ::"v"(wc[3].w));  // the prefetched weights (and the patch before them) have arrived
+#endif
+    DTW_STAMP(0);  // wait for the prefetched global data + patch -> LDS
     if (!(DT_WABL & 8)) __syncthreads();  // patch visible; everyone is done with this buffer from two iterations ago
+    DTW_STAMP(1);  // barrier
     if (g + g_stride < a.groups) DTW_PREFETCH(g + g_stride);
+    DTW_STAMP(2);  // issue of the next step's global loads
     // B^T d B restricted to transform row `wave`
     float4 tcol[4];
 #pragma unroll
@@ -789,6 +811,10 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
     V[1] = make_float4(tcol[1].x + tcol[2].x, tcol[1].y + tcol[2].y, tcol[1].z + tcol[2].z, tcol[1].w + tcol[2].w);
     V[2] = make_float4(tcol[2].x - tcol[1].x, tcol[2].y - tcol[1].y, tcol[2].z - tcol[1].z, tcol[2].w - tcol[1].w);
     V[3] = make_float4(tcol[1].x - tcol[3].x, tcol[1].y - tcol[3].y, tcol[1].z - tcol[3].z, tcol[1].w - tcol[3].w);
+#ifdef DT_CONV_TIMING
+    asm volatile("s_nop 0" ::"v"(V[0].x), "v"(V[1].y), "v"(V[2].z), "v"(V[3].w));
+#endif
+    DTW_STAMP(3);  // LDS window reads + input transform
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[b].x, V[b].x, acc[b], 0, 0, 0);
@@ -796,7 +822,17 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
       acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[b].z, V[b].z, acc[b], 0, 0, 0);
       acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[b].w, V[b].w, acc[b], 0, 0, 0);
     }
+    DTW_STAMP(4);  // issue of the 16 MFMAs (an MFMA issues when the pipe takes it)
   }
+#ifdef DT_CONV_TIMING
+  if (a.timing && (threadIdx.x & 63) == 0 && wave == DT_WINO_TIMING_WAVE && ks == 0) {
+    unsigned long long* o = a.timing + (size_t)vblock * 8;
+    o[0] = tbegin;
+    o[1] = tph[0]; o[2] = tph[1]; o[3] = tph[2]; o[4] = tph[3]; o[5] = tph[4];
+    o[6] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+#undef DTW_STAMP
 #undef DTW_PREFETCH
 
   // ---- inverse transform: columns in registers, rows across the four waves through LDS ----------------
