@@ -92,7 +92,9 @@ int dt_cv_dot_stats_f32(const float* cur_feats_bchw, const float* src_feats_bkhw
  *     layouts, row-major) or NULL;
  *   depth_hint / hint_weights / hint_mask: [b,1,hint_h,hint_w] maps (NaN allowed where mask==0),
  *     ignored when hint_mlp == NULL;
- *   out_nhwc: 0 -> volume [b,D,h,w]; 1 -> [b,h,w,D] (torch channels_last of the same tensor).
+ *   out_nhwc: 0 -> volume [b,D,h,w]; 1 -> [b,h,w,D] (torch channels_last of the same tensor);
+ *   num_src: 1..15 source views -- up to 7 (the reference default) every view's layer-1 weights stay resident in LDS, the
+ *     views beyond the seventh read theirs from L2 inside the view loop.
  */
 int dt_cv_mlp_pack_floats(int num_src, int* w1dyn, int* w1pix, int* w2p, int* tail);
 int dt_cv_mlp_hint_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc,

@@ -37,7 +37,8 @@ def test_argument_errors_are_reported_not_launched():
     assert L.dt_cv_dot_f32(None, None, None, None, 1, 7, 12, 4, 4, 8, None) != 0
     assert b"channels" in L.dt_last_error() or b"null" in L.dt_last_error()
     n = ctypes.c_int()
-    assert L.dt_cv_mlp_pack_floats(9, ctypes.byref(n), None, None, None) != 0
+    assert L.dt_cv_mlp_pack_floats(16, ctypes.byref(n), None, None, None) != 0   # the fused kernel takes 1..15 source views
+    assert L.dt_cv_mlp_pack_floats(9, ctypes.byref(n), None, None, None) == 0 and n.value == 9 * 12 * 256
     assert L.dt_cv_mlp_pack_floats(7, ctypes.byref(n), None, None, None) == 0 and n.value == 7 * 12 * 256
     assert L.dt_conv_pack_floats(64, 64, 3) == 64 * 64 * 9
     d = _abi.ConvDesc()
