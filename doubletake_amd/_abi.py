@@ -44,6 +44,7 @@ SIGNATURES = {
     "dt_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dt_cv_params_floats": (_I, [_I, _I]),
     "dt_cv_setup_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "dt_cv_relative_poses_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "dt_cv_warp_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dt_cv_dot_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dt_cv_dot_direct_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

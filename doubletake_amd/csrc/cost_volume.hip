@@ -15,6 +15,28 @@
 namespace dt {
 
 // ------------------------------------------------------------------------------------------
+// relative poses of a keyframe tuple: src_cam_T_cur_cam = src_cam_T_world @ cur_world_T_cam and
+// cur_cam_T_src_cam = cur_cam_T_world @ src_world_T_cam (doubletake_model.py:330-339).  The reference issues two
+// torch.matmul calls on [b,K,4,4] tensors; on ROCm each is a hipBLASLt launch with ~100 us of host-side set-up, which sat
+// on the per-frame critical path of the incremental loop (profiles/r3q_incremental_frame_timeline.txt).  One thread per
+// output element here.
+// ------------------------------------------------------------------------------------------
+__global__ void cv_relative_poses_kernel(const float* __restrict__ src_cTw, const float* __restrict__ src_wTc,
+                                         const float* __restrict__ cur_cTw, const float* __restrict__ cur_wTc, int B, int K,
+                                         float* __restrict__ ext, float* __restrict__ poses) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * K * 16) return;
+  const int e = idx & 15, bk = idx >> 4, b = bk / K;
+  const int i = e >> 2, j = e & 3;
+  const float* A = src_cTw + (size_t)bk * 16;  // ext = A @ Bm
+  const float* Bm = cur_wTc + (size_t)b * 16;
+  ext[idx] = A[i * 4 + 0] * Bm[0 * 4 + j] + A[i * 4 + 1] * Bm[1 * 4 + j] + A[i * 4 + 2] * Bm[2 * 4 + j] + A[i * 4 + 3] * Bm[3 * 4 + j];
+  const float* Cm = cur_cTw + (size_t)b * 16;  // poses = Cm @ Dm
+  const float* Dm = src_wTc + (size_t)bk * 16;
+  poses[idx] = Cm[i * 4 + 0] * Dm[0 * 4 + j] + Cm[i * 4 + 1] * Dm[1 * 4 + j] + Cm[i * 4 + 2] * Dm[2 * 4 + j] + Cm[i * 4 + 3] * Dm[3 * 4 + j];
+}
+
+// ------------------------------------------------------------------------------------------
 // setup: one block per batch element, thread k handles source view k; thread-strided planes
 // ------------------------------------------------------------------------------------------
 __global__ void cv_setup_kernel(const float* __restrict__ src_Ks, const float* __restrict__ src_ext,
@@ -316,6 +338,19 @@ int dt_cv_setup_f32(const float* src_Ks, const float* src_ext, const float* src_
   DT_LAUNCH(cv_setup_kernel, dim3(batch), dim3(64), 0, to_stream(s), src_Ks, src_ext, src_poses, cur_invK,
                      min_depth, max_depth, num_src, num_planes, params_out);
   return check_launch("dt_cv_setup_f32");
+}
+
+int dt_cv_relative_poses_f32(const float* src_cam_T_world_bk44, const float* src_world_T_cam_bk44,
+                             const float* cur_cam_T_world_b44, const float* cur_world_T_cam_b44, int batch, int num_src,
+                             float* src_cam_T_cur_cam_bk44, float* cur_cam_T_src_cam_bk44, dt_stream_t s) {
+  DT_REQUIRE(batch > 0 && num_src > 0, "dt_cv_relative_poses_f32: bad extents");
+  DT_REQUIRE(src_cam_T_world_bk44 && src_world_T_cam_bk44 && cur_cam_T_world_b44 && cur_world_T_cam_b44 && src_cam_T_cur_cam_bk44 &&
+                 cur_cam_T_src_cam_bk44,
+             "dt_cv_relative_poses_f32: null pointer");
+  const int n = batch * num_src * 16;
+  DT_LAUNCH(cv_relative_poses_kernel, dim3((n + 255) / 256), dim3(256), 0, to_stream(s), src_cam_T_world_bk44, src_world_T_cam_bk44,
+            cur_cam_T_world_b44, cur_world_T_cam_b44, batch, num_src, src_cam_T_cur_cam_bk44, cur_cam_T_src_cam_bk44);
+  return check_launch("dt_cv_relative_poses_f32");
 }
 
 int dt_cv_warp_f32(const float* src_bkchw, const float* params, const float* depth_bhw, int batch, int num_src,

@@ -168,16 +168,14 @@ class _HotPathDepthModel(nn.Module):
         bits (different K-split of the same fp32 sums), exactly like the reference's unbatched flag."""
         if self.matching_model is None:
             raise RuntimeError("this model was built without a matching encoder")
-        frames = torch.cat([cur_image.unsqueeze(1), src_image], dim=1)
-        b, m = frames.shape[:2]
-        flat = frames.flatten(0, 1)
+        b, m = cur_image.shape[0], src_image.shape[1] + 1
         if cur_ids is not None and src_ids is not None:
             ids = [[cur_ids[i]] + [src_ids[k][i] for k in range(m - 1)] for i in range(b)]
             scans = [scan_ids] * b if isinstance(scan_ids, str) or scan_ids is None else list(scan_ids)
             flat_ids = [(scans[i], fid) for i, row in enumerate(ids) for fid in row]
             cache = self.matching_feature_cache
             # entries are only valid for the weights (and the image size) they were computed with
-            token = self._cache_token(flat.shape[1:], flat.device)
+            token = self._cache_token(cur_image.shape[1:], cur_image.device)
             if cache.token != token:
                 cache.clear()
                 cache.token = token
@@ -187,14 +185,25 @@ class _HotPathDepthModel(nn.Module):
                 first.setdefault(flat_ids[j], j)
             todo = sorted(first.values())
             if todo:
-                new = self._encode(flat[todo])
+                # only the images that are actually encoded are gathered (views of the two input tensors: no copy of the
+                # whole [b, 1+K] image tuple, which is 29 MB per keyframe at 640x480)
+                pick = lambda j: cur_image[j // m] if j % m == 0 else src_image[j // m, j % m - 1]
+                imgs = pick(todo[0]).unsqueeze(0) if len(todo) == 1 else torch.stack([pick(j) for j in todo], 0)
+                new = self._encode(imgs)
                 for row, j in enumerate(todo):
                     cache.put(flat_ids[j], new[row])
-            feats = torch.stack([cache.get(fid) for fid in flat_ids], dim=0)
-        elif unbatched_matching_encoder_forward:
-            feats = torch.cat([self.matching_model(f) for f in flat.split(1, dim=0)], dim=0)
+            # the cached maps are gathered straight into the two tensors the volume takes (one stack for the source views,
+            # none for the current view at batch 1) -- not stacked as one [b*(1+K)] tensor and sliced apart again
+            got = [cache.get(fid) for fid in flat_ids]
+            cur_f = got[0].unsqueeze(0) if b == 1 else torch.stack([got[i * m] for i in range(b)], 0)
+            src_f = torch.stack([got[i * m + 1 + k] for i in range(b) for k in range(m - 1)], 0)
+            return cur_f, src_f.view(b, m - 1, *src_f.shape[1:])
         else:
-            feats = self.matching_model(flat)
+            flat = torch.cat([cur_image.unsqueeze(1), src_image], dim=1).flatten(0, 1)
+            if unbatched_matching_encoder_forward:
+                feats = torch.cat([self.matching_model(f) for f in flat.split(1, dim=0)], dim=0)
+            else:
+                feats = self.matching_model(flat)
         feats = feats.view(b, m, *feats.shape[1:])
         return feats[:, 0], feats[:, 1:].contiguous()
 
@@ -344,6 +353,27 @@ class _HotPathDepthModel(nn.Module):
         depth_outputs["overall_mask_bhw"] = overall_mask
         return depth_outputs
 
+    @staticmethod
+    @torch.no_grad()
+    def relative_poses(cur_data, src_data):
+        """(src_cam_T_cur_cam, cur_cam_T_src_cam), reference doubletake_model.py:330-339 -- there two torch.matmul calls on
+        [b,K,4,4] tensors; one HIP launch here (a 4x4 matmul through hipBLASLt costs ~100 us of host time on ROCm)."""
+        from .. import _abi
+
+        src_cTw, src_wTc = src_data["cam_T_world_b44"], src_data["world_T_cam_b44"]
+        cur_cTw, cur_wTc = cur_data["cam_T_world_b44"], cur_data["world_T_cam_b44"]
+        if not src_cTw.is_cuda:
+            raise _abi.DoubletakeHipError("camera matrices are on the CPU; doubletake_amd only runs on a ROCm GPU (no CPU fallback)")
+        f = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+        src_cTw, src_wTc, cur_cTw, cur_wTc = f(src_cTw), f(src_wTc), f(cur_cTw), f(cur_wTc)
+        b, k = src_cTw.shape[:2]
+        ext = torch.empty_like(src_cTw)
+        poses = torch.empty_like(src_cTw)
+        _abi.check(_abi.lib().dt_cv_relative_poses_f32(_abi.ptr(src_cTw), _abi.ptr(src_wTc), _abi.ptr(cur_cTw), _abi.ptr(cur_wTc),
+                                                       b, k, _abi.ptr(ext), _abi.ptr(poses), _abi.current_stream(src_cTw.device)),
+                   "dt_cv_relative_poses_f32")
+        return ext, poses
+
     @torch.no_grad()
     def forward(self, phase, cur_data, src_data, unbatched_matching_encoder_forward=False, return_mask=False):
         """Reference signature (doubletake_model.py:265).  Needs self.encoder (the timm image encoder)."""
@@ -352,8 +382,7 @@ class _HotPathDepthModel(nn.Module):
         s = self.matching_scale
         src_K = src_data[f"K_s{s}_b44"]
         cur_invK = cur_data[f"invK_s{s}_b44"]
-        src_cam_T_cur_cam = src_data["cam_T_world_b44"] @ cur_data["world_T_cam_b44"].unsqueeze(1)
-        cur_cam_T_src_cam = cur_data["cam_T_world_b44"].unsqueeze(1) @ src_data["world_T_cam_b44"]
+        src_cam_T_cur_cam, cur_cam_T_src_cam = self.relative_poses(cur_data, src_data)
         cur_feats = self.encoder(cur_data["image_b3hw"])
         ids = {}
         if getattr(self, "use_feature_cache", False) and "frame_id_string" in cur_data and "frame_id_string" in src_data:

@@ -56,6 +56,12 @@ int dt_cv_setup_f32(const float* src_Ks_bk44, const float* src_extrinsics_bk44,
                     const float* min_depth_b, const float* max_depth_b,
                     int batch, int num_src, int num_planes, float* params_out, dt_stream_t s);
 
+/* replaces: the two torch.matmul calls on the tuple's 4x4 camera matrices in DepthModelCVHint.forward
+ * (experiment_modules/doubletake_model.py:330-339): src_cam_T_cur_cam[b,k] = src_cam_T_world[b,k] @ cur_world_T_cam[b] and
+ * cur_cam_T_src_cam[b,k] = cur_cam_T_world[b] @ src_world_T_cam[b,k], fp32, row-major 4x4, in one launch. */
+int dt_cv_relative_poses_f32(const float* src_cam_T_world_bk44, const float* src_world_T_cam_bk44,
+                             const float* cur_cam_T_world_b44, const float* cur_world_T_cam_b44, int batch, int num_src,
+                             float* src_cam_T_cur_cam_bk44, float* cur_cam_T_src_cam_bk44, dt_stream_t s);
 /* replaces: CostVolumeManager.warp_features (modules/cost_volume.py:132-217) as a stand-alone op: warp every
  * source view to the current view at ONE depth map per batch element.  src NCHW [b,k,c,h,w]; params from
  * dt_cv_setup_f32 (num_planes = the D it was built with); outputs: world points [b*k,4,h*w], projected depths

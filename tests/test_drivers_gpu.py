@@ -98,8 +98,9 @@ def test_reference_shaped_forward_equals_forward_from_features():
     # the same through the parts
     feats = model.encoder(cur["image_b3hw"])
     m_cur, m_src = model.compute_matching_feats(cur["image_b3hw"], src["image_b3hw"])
-    ext = src["cam_T_world_b44"] @ cur["world_T_cam_b44"].unsqueeze(1)
-    poses = cur["cam_T_world_b44"].unsqueeze(1) @ src["world_T_cam_b44"]
+    ext, poses = model.relative_poses(cur, src)   # one HIP launch instead of the reference's two torch.matmul calls
+    assert torch.allclose(ext, src["cam_T_world_b44"] @ cur["world_T_cam_b44"].unsqueeze(1), atol=1e-6)
+    assert torch.allclose(poses, cur["cam_T_world_b44"].unsqueeze(1) @ src["world_T_cam_b44"], atol=1e-6)
     want = model.forward_from_features(feats, m_cur, m_src, ext, poses, src["K_s1_b44"], cur["invK_s1_b44"], cur, return_mask=True)
     for key in want:
         assert torch.equal(out[key], want[key]), key
