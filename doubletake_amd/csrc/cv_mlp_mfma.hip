@@ -24,6 +24,11 @@
 // plane.  One 256-thread workgroup per CU keeps the plane-dependent layer-1 weights, layer-2
 // weights and the tail (b2, W3, b3) resident in LDS (152.6 KB for K=7).
 #include <cstdlib>
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "common.hpp"
 #include "cv_geometry.hpp"
@@ -64,6 +69,7 @@ struct MlpArgs {
   int out_nhwc;
   int B, K, h, w, D;
   int num_tiles;          // 32-pixel tiles per batch element
+  const int* tile_order;  // [num_tiles] position in the processing order -> tile, or null (row-major order)
   long total_units;       // B * num_tiles * D (tile, plane) units, split evenly over the resident waves
 };
 
@@ -228,8 +234,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   // partial tiles.  (With a fixed planes-per-task granularity the B=1 case left up to 25 % of the
   // waves one task short of the others.)
   // XCD-aware order (blocks are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2): give
-  // every XCD one contiguous eighth of the span space, i.e. a band of image rows, so that the
-  // source-feature footprint of an XCD fits its L2 instead of every XCD streaming all 7 views.
+  // every XCD one contiguous eighth of the span space so that the source-feature footprint of an XCD
+  // fits its L2 instead of every XCD streaming all 7 views.  The span space runs over the tiles in
+  // a.tile_order (column strips walked boustrophedon, see mlp_tile_order below), so an eighth is a
+  // compact block of the image, not a band of rows.
   const int nblk = gridDim.x;
   const int lbid = (nblk % 8 == 0) ? (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   const long wid = (long)lbid * NWAVES + wave;
@@ -238,18 +246,19 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   // VALU results, i.e. VGPRs -- out of the loop and carry them, spilled, through every plane loop.)  Integer division runs
   // on the VALU, which also makes its results "divergent" to the compiler; readfirstlane restores wave-uniformity so that
   // the per-view parameter reads below are scalar loads (SGPR operands, scalar cache).
-  int remaining, d0, tile, b;
+  int remaining, d0, otile, b;  // otile: position in the tile order
   {
     const long u = wid * a.total_units / waves_total;
     const long u_end = (wid + 1) * a.total_units / waves_total;
     const long tile_global = u / D;
     d0 = __builtin_amdgcn_readfirstlane((int)(u - tile_global * D));
-    tile = __builtin_amdgcn_readfirstlane((int)(tile_global % a.num_tiles));
+    otile = __builtin_amdgcn_readfirstlane((int)(tile_global % a.num_tiles));
     b = __builtin_amdgcn_readfirstlane((int)(tile_global / a.num_tiles));
     remaining = __builtin_amdgcn_readfirstlane((int)(u_end - u));
   }
   for (; remaining > 0;) {
     const int d1 = min(D, d0 + remaining);
+    const int tile = a.tile_order ? ((const int __attribute__((address_space(4)))*)(uintptr_t)a.tile_order)[otile] : otile;  // (wave-uniform: one scalar load per task)
     const cfloat_ptr p = as_const(a.params + (size_t)b * cv_params_floats(D, K));
     const float* src_b = a.src + (size_t)b * K * hw * kF;
 
@@ -543,14 +552,69 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
     d0 = d1;
     if (d0 == D) {
       d0 = 0;
-      if (++tile == a.num_tiles) {
-        tile = 0;
+      if (++otile == a.num_tiles) {
+        otile = 0;
         ++b;
       }
     }
   }
 }
 
+
+// Tile processing order.  A wave's span and an XCD's eighth of the span space are contiguous in this order, and every XCD
+// fetches the source texels its eighth's epipolar segments touch into its own L2.  Row-major order makes an eighth a band of
+// h/8 rows over the full width, whose footprint under a horizontal baseline is fine but under any vertical parallax covers
+// most of the source map in all eight L2s.  Column strips of one tile width, walked down / up alternately, make an eighth a
+// compact block (about 40 x 60 pixels at 160 x 120): the summed footprint of the eight XCDs on the bench geometry drops from
+// 25.5 MB to 16.9 MB (7.9 MB is one copy; scripts/volume_footprint.py).  Results do not depend on the order.
+// The table lives in device memory per (device, h, w), built on first use with a blocking copy (visible to every stream
+// afterwards); a first use that happens during a stream capture keeps the row-major order instead of allocating.
+struct TileOrderKey {
+  int dev, h, w;
+  bool operator<(const TileOrderKey& o) const { return dev != o.dev ? dev < o.dev : (h != o.h ? h < o.h : w < o.w); }
+};
+static std::mutex g_order_mutex;
+static std::map<TileOrderKey, int*> g_tile_orders;
+static const bool g_tile_order_on = [] { const char* e = getenv("DT_MLP_TILE_ORDER"); return !(e && e[0] == '0'); }();
+
+static const int* mlp_tile_order(int h, int w, hipStream_t st) {
+  if (!g_tile_order_on) return nullptr;
+  const int num_tiles = (int)(((long)h * w + 31) / 32);
+  if (num_tiles < 64) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_order_mutex);
+  const TileOrderKey key{dev, h, w};
+  auto it = g_tile_orders.find(key);
+  if (it != g_tile_orders.end()) return it->second;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;  // (not cached: the next eager call builds it)
+  }
+  // sort key of a tile: (column strip of its first pixel, row -- descending in odd strips)
+  std::vector<std::pair<long, int>> keyed(num_tiles);
+  for (int t = 0; t < num_tiles; ++t) {
+    const long p = (long)t * 32;
+    const int y = (int)(p / w), strip = (int)(p % w) / 32;
+    keyed[t] = std::make_pair((long)strip * (h + 1) + ((strip & 1) ? h - y : y), t);
+  }
+  std::sort(keyed.begin(), keyed.end());
+  std::vector<int> order(num_tiles);
+  for (int i = 0; i < num_tiles; ++i) order[i] = keyed[i].second;
+  int* dptr = nullptr;
+  if (hipMalloc(&dptr, num_tiles * sizeof(int)) != hipSuccess ||
+      hipMemcpy(dptr, order.data(), num_tiles * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    if (dptr) (void)hipFree(dptr);
+    dptr = nullptr;
+  }
+  g_tile_orders[key] = dptr;  // (a failed allocation is remembered as "row-major")
+  return dptr;
+}
 
 // waves per workgroup of the fused kernel (4 = one per SIMD, 8 = two per SIMD); DT_MLP_WAVES overrides
 static int g_mlp_waves = [] { const char* e = getenv("DT_MLP_WAVES"); return (e && e[0] == '4') ? 4 : 8; }();
@@ -588,6 +652,7 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
   a.B = batch; a.K = num_src; a.h = h; a.w = w; a.D = num_planes;
   const long hw = (long)h * w;
   a.num_tiles = (int)((hw + 31) / 32);
+  a.tile_order = mlp_tile_order(h, w, to_stream(s));
   const int cus = num_cus();
   a.total_units = (long)batch * a.num_tiles * num_planes;
   const int nw = (num_src > kMaxSrcMfma) ? 4 : g_mlp_waves;  // streamed views: one wave per SIMD (register room for the loads in flight)
