@@ -53,9 +53,10 @@ SIGNATURES = {
     "dt_cv_mlp_hint_f32": (_I, [_P] * 11 + [_I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dt_cv_mlp_split_pack_halves": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "dt_cv_mlp_hint_split_f32": (_I, [_P] * 11 + [_I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "dt_cv_mlp_hint_simple_f32": (_I, [_P] * 13 + [_I, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "dt_cv_lowest_cost_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "dt_cv_overall_mask_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dt_cv_mlp_hint_simple_f32": (_I, [_P] * 14 + [_I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dt_cv_dot_simple_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dt_cv_lowest_cost_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dt_cv_overall_mask_u8": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dt_conv_pack_floats": (_L, [_I, _I, _I]),
     "dt_conv_pack_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "dt_conv2d_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -130,15 +130,23 @@ __global__ __launch_bounds__(256) void cv_warp_kernel(const float* __restrict__ 
 // Input-vector channel order follows modules/mesh_hint_volume.py:353-370.
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxSrc = 16;
-constexpr int kFeat = 16;
+constexpr int kMaxFeatSimple = 32;  // matching_dim_size accepted by the one-thread-per-sample kernels
 constexpr int kHidden = 128;
+
+// depth of plane d at a pixel: the per-batch plane list of the parameter block, or -- when the caller handed its own
+// depth_planes_bdhw (modules/cost_volume.py:249-250, feature_volume.py:145-146, mesh_hint_volume.py:149-150) -- that tensor
+__device__ __forceinline__ float plane_depth(const float* __restrict__ p, const float* __restrict__ planes_bdhw, int b,
+                                             int d, int D, size_t hw, size_t pix) {
+  return planes_bdhw ? planes_bdhw[((size_t)b * D + d) * hw + pix] : p[kCvPlanes + d];
+}
 
 __global__ __launch_bounds__(128) void cv_mlp_simple_kernel(
     const float* __restrict__ cur_bchw, const float* __restrict__ src_bkhwc, const float* __restrict__ params,
-    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
-    const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
+    const float* __restrict__ planes_bdhw, const float* __restrict__ W1, const float* __restrict__ b1,
+    const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
     const float* __restrict__ hint_mlp, const float* __restrict__ depth_hint, const float* __restrict__ hint_w,
-    const float* __restrict__ hint_m, int hint_h, int hint_w2, float* __restrict__ vol, int K, int h, int w, int D) {
+    const float* __restrict__ hint_m, int hint_h, int hint_w2, float* __restrict__ vol, int K, int nfeat, int h, int w,
+    int D) {
   const int b = blockIdx.z;
   const int d = blockIdx.y;
   const size_t hw = (size_t)h * w;
@@ -146,22 +154,22 @@ __global__ __launch_bounds__(128) void cv_mlp_simple_kernel(
   if (pix >= hw) return;
   const int y = (int)(pix / w), x = (int)(pix % w);
   const float* p = params + (size_t)b * cv_params_floats(D, K);
-  const int Cin = 20 * (K + 1) + 6 * K;
+  const int Cin = (nfeat + 4) * (K + 1) + 6 * K;
 
-  float in[20 * (kMaxSrc + 1) + 6 * kMaxSrc];
+  float in[(kMaxFeatSimple + 4) * (kMaxSrc + 1) + 6 * kMaxSrc];
   float rx, ry, rz;
   pixel_ray(p + kCvInvK, x, y, rx, ry, rz);
-  const float depth = p[kCvPlanes + d];
+  const float depth = plane_depth(p, planes_bdhw, b, d, D, hw, pix);
   const float X = depth * rx, Y = depth * ry, Z = depth * rz;
   float cx = X, cy = Y, cz = Z;
   normalize3(cx, cy, cz);
   const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
 
-  const int o_cur = kFeat * K, o_mask = o_cur + kFeat, o_z = o_mask + K, o_plane = o_z + K;
+  const int o_cur = nfeat * K, o_mask = o_cur + nfeat, o_z = o_mask + K, o_plane = o_z + K;
   const int o_dot = o_plane + 1, o_ang = o_dot + K, o_cray = o_ang + K, o_sray = o_cray + 3;
   const int o_pd = o_sray + 3 * K, o_R = o_pd + K, o_t = o_R + K;
 
-  for (int c = 0; c < kFeat; ++c) in[o_cur + c] = cur_bchw[((size_t)b * kFeat + c) * hw + pix];
+  for (int c = 0; c < nfeat; ++c) in[o_cur + c] = cur_bchw[((size_t)b * nfeat + c) * hw + pix];
   in[o_plane] = depth;
   in[o_cray + 0] = cx;
   in[o_cray + 1] = cy;
@@ -170,15 +178,15 @@ __global__ __launch_bounds__(128) void cv_mlp_simple_kernel(
     const float* vp = p + cv_view_off(D, k);
     const ViewProj q = project_view(vp, X, Y, Z);
     const Taps t = bilinear_taps(q.u, q.v, h, w, inv_w, inv_h);
-    const float* base = src_bkhwc + ((size_t)b * K + k) * hw * kFeat;
-    const float* p00 = base + ((size_t)t.y0 * w + t.x0) * kFeat;
-    const float* p01 = base + ((size_t)t.y0 * w + t.x1) * kFeat;
-    const float* p10 = base + ((size_t)t.y1 * w + t.x0) * kFeat;
-    const float* p11 = base + ((size_t)t.y1 * w + t.x1) * kFeat;
+    const float* base = src_bkhwc + ((size_t)b * K + k) * hw * nfeat;
+    const float* p00 = base + ((size_t)t.y0 * w + t.x0) * nfeat;
+    const float* p01 = base + ((size_t)t.y0 * w + t.x1) * nfeat;
+    const float* p10 = base + ((size_t)t.y1 * w + t.x0) * nfeat;
+    const float* p11 = base + ((size_t)t.y1 * w + t.x1) * nfeat;
     float dot = 0.f;
-    for (int c = 0; c < kFeat; ++c) {
+    for (int c = 0; c < nfeat; ++c) {
       const float f = p00[c] * t.w00 + p01[c] * t.w01 + p10[c] * t.w10 + p11[c] * t.w11;
-      in[k * kFeat + c] = f;
+      in[k * nfeat + c] = f;
       dot += f * in[o_cur + c];
     }
     const float m = (q.z > 0.f) ? 1.f : 0.f;
@@ -222,10 +230,52 @@ __global__ __launch_bounds__(128) void cv_mlp_simple_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// simple dot-product volume: one thread per (pixel, plane), any channel count, optional per-pixel planes.
+// modules/cost_volume.py:219-315 for the shapes the tuned kernel (cv_dot_lds.hip: 16 channels, one plane list per
+// batch element) does not take.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void cv_dot_simple_kernel(const float* __restrict__ cur_bchw,
+                                                             const float* __restrict__ src_bkhwc,
+                                                             const float* __restrict__ params,
+                                                             const float* __restrict__ planes_bdhw, float* __restrict__ vol,
+                                                             int K, int C, int h, int w, int D) {
+  const int b = blockIdx.z;
+  const int d = blockIdx.y;
+  const size_t hw = (size_t)h * w;
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= hw) return;
+  const int y = (int)(pix / w), x = (int)(pix % w);
+  const float* p = params + (size_t)b * cv_params_floats(D, K);
+  float rx, ry, rz;
+  pixel_ray(p + kCvInvK, x, y, rx, ry, rz);
+  const float depth = plane_depth(p, planes_bdhw, b, d, D, hw, pix);
+  const float X = depth * rx, Y = depth * ry, Z = depth * rz;
+  const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
+  float sum = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const ViewProj q = project_view(p + cv_view_off(D, k), X, Y, Z);
+    const Taps t = bilinear_taps(q.u, q.v, h, w, inv_w, inv_h);
+    const float* base = src_bkhwc + ((size_t)b * K + k) * hw * C;
+    const float* p00 = base + ((size_t)t.y0 * w + t.x0) * C;
+    const float* p01 = base + ((size_t)t.y0 * w + t.x1) * C;
+    const float* p10 = base + ((size_t)t.y1 * w + t.x0) * C;
+    const float* p11 = base + ((size_t)t.y1 * w + t.x1) * C;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float f = p00[c] * t.w00 + p01[c] * t.w01 + p10[c] * t.w10 + p11[c] * t.w11;
+      dot += f * cur_bchw[((size_t)b * C + c) * hw + pix];
+    }
+    sum += (q.z > 0.f) ? dot : 0.f;
+  }
+  vol[((size_t)b * D + d) * hw + pix] = sum;
+}
+
+// ------------------------------------------------------------------------------------------
 // lowest cost: plane depth at the first maximum over d
 // ------------------------------------------------------------------------------------------
 __global__ void cv_lowest_cost_kernel(const float* __restrict__ vol, const float* __restrict__ params,
-                                      float* __restrict__ out, int nhwc, int K, size_t hw, int D) {
+                                      const float* __restrict__ planes_bdhw, float* __restrict__ out, int nhwc, int K,
+                                      size_t hw, int D) {
   const int b = blockIdx.y;
   const float* p = params + (size_t)b * cv_params_floats(D, K);
   if (nhwc) {
@@ -271,7 +321,7 @@ __global__ void cv_lowest_cost_kernel(const float* __restrict__ vol, const float
         nan_seen = on != 0;
       }
     }
-    if (pix < hw && sub == 0) out[(size_t)b * hw + pix] = p[kCvPlanes + (bi == 0x7fffffff ? 0 : bi)];
+    if (pix < hw && sub == 0) out[(size_t)b * hw + pix] = plane_depth(p, planes_bdhw, b, bi == 0x7fffffff ? 0 : bi, D, hw, pix);
     return;
   }
   const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,14 +340,14 @@ __global__ void cv_lowest_cost_kernel(const float* __restrict__ vol, const float
       bi = d;
     }
   }
-  out[(size_t)b * hw + pix] = p[kCvPlanes + bi];
+  out[(size_t)b * hw + pix] = plane_depth(p, planes_bdhw, b, bi, D, hw, pix);
 }
 
 // ------------------------------------------------------------------------------------------
 // overall mask at the last plane
 // ------------------------------------------------------------------------------------------
-__global__ void cv_mask_kernel(const float* __restrict__ params, uint8_t* __restrict__ out, int per_view,
-                               int K, int h, int w, int D) {
+__global__ void cv_mask_kernel(const float* __restrict__ params, const float* __restrict__ planes_bdhw,
+                               uint8_t* __restrict__ out, int per_view, int K, int h, int w, int D) {
   const int b = blockIdx.y;
   const size_t hw = (size_t)h * w;
   const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -306,7 +356,7 @@ __global__ void cv_mask_kernel(const float* __restrict__ params, uint8_t* __rest
   const float* p = params + (size_t)b * cv_params_floats(D, K);
   float rx, ry, rz;
   pixel_ray(p + kCvInvK, x, y, rx, ry, rz);
-  const float depth = p[kCvPlanes + D - 1];
+  const float depth = plane_depth(p, planes_bdhw, b, D - 1, D, hw, pix);
   const float X = depth * rx, Y = depth * ry, Z = depth * rz;
   bool any_d = false, any_b = false;
   for (int k = 0; k < K; ++k) {
@@ -366,44 +416,57 @@ int dt_cv_warp_f32(const float* src_bkchw, const float* params, const float* dep
   return check_launch("dt_cv_warp_f32");
 }
 
-int dt_cv_mlp_hint_simple_f32(const float* cur, const float* src, const float* params, const float* W1,
-                              const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
-                              const float* hint_mlp, const float* depth_hint, const float* hint_w,
-                              const float* hint_m, int hint_h, int hint_w2, float* vol, int batch, int num_src, int h, int w,
-                              int num_planes, dt_stream_t s) {
+int dt_cv_dot_simple_f32(const float* cur, const float* src, const float* params, const float* depth_planes_bdhw,
+                         float* vol, int batch, int num_src, int channels, int h, int w, int num_planes, dt_stream_t s) {
+  DT_REQUIRE(batch > 0 && num_src > 0 && channels > 0 && h > 0 && w > 0 && num_planes > 0, "dt_cv_dot_simple_f32: bad extents");
+  DT_REQUIRE(cur && src && params && vol, "dt_cv_dot_simple_f32: null pointer");
+  const size_t hw = (size_t)h * w;
+  dim3 grid((unsigned)((hw + 127) / 128), num_planes, batch);
+  DT_LAUNCH(cv_dot_simple_kernel, grid, dim3(128), 0, to_stream(s), cur, src, params, depth_planes_bdhw, vol, num_src,
+            channels, h, w, num_planes);
+  return check_launch("dt_cv_dot_simple_f32");
+}
+
+int dt_cv_mlp_hint_simple_f32(const float* cur, const float* src, const float* params, const float* depth_planes_bdhw,
+                              const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                              const float* b3, const float* hint_mlp, const float* depth_hint, const float* hint_w,
+                              const float* hint_m, int hint_h, int hint_w2, float* vol, int batch, int num_src, int channels,
+                              int h, int w, int num_planes, dt_stream_t s) {
   DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0, "dt_cv_mlp_hint_simple_f32: bad extents");
   DT_REQUIRE(num_src > 0 && num_src <= kMaxSrc, "dt_cv_mlp_hint_simple_f32: num_src=%d not in 1..%d", num_src,
              kMaxSrc);
+  DT_REQUIRE(channels > 0 && channels <= kMaxFeatSimple, "dt_cv_mlp_hint_simple_f32: channels=%d not in 1..%d", channels,
+             kMaxFeatSimple);
   DT_REQUIRE(cur && src && params && W1 && b1 && W2 && b2 && W3 && b3 && vol, "dt_cv_mlp_hint_simple_f32: null pointer");
   DT_REQUIRE(hint_mlp == nullptr || (depth_hint && hint_w && hint_m && hint_h > 0 && hint_w2 > 0),
              "dt_cv_mlp_hint_simple_f32: hint MLP given without hint maps");
   const size_t hw = (size_t)h * w;
   dim3 grid((unsigned)((hw + 127) / 128), num_planes, batch);
-  DT_LAUNCH(cv_mlp_simple_kernel, grid, dim3(128), 0, to_stream(s), cur, src, params, W1, b1, W2, b2, W3, b3,
-                     hint_mlp, depth_hint, hint_w, hint_m, hint_h, hint_w2, vol, num_src, h, w, num_planes);
+  DT_LAUNCH(cv_mlp_simple_kernel, grid, dim3(128), 0, to_stream(s), cur, src, params, depth_planes_bdhw, W1, b1, W2, b2, W3,
+            b3, hint_mlp, depth_hint, hint_w, hint_m, hint_h, hint_w2, vol, num_src, channels, h, w, num_planes);
   return check_launch("dt_cv_mlp_hint_simple_f32");
 }
 
-int dt_cv_lowest_cost_f32(const float* volume, const float* params, float* lowest, int nhwc, int batch, int num_src,
-                          int h, int w, int num_planes, dt_stream_t s) {
+int dt_cv_lowest_cost_f32(const float* volume, const float* params, const float* depth_planes_bdhw, float* lowest, int nhwc,
+                          int batch, int num_src, int h, int w, int num_planes, dt_stream_t s) {
   DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0 && num_src > 0, "dt_cv_lowest_cost_f32: bad extents");
   DT_REQUIRE(volume && params && lowest, "dt_cv_lowest_cost_f32: null pointer");
   const size_t hw = (size_t)h * w;
   const size_t threads = nhwc ? hw * 16 : hw;
   dim3 grid((unsigned)((threads + 255) / 256), batch);
-  DT_LAUNCH(cv_lowest_cost_kernel, grid, dim3(256), 0, to_stream(s), volume, params, lowest, nhwc, num_src, hw,
-                     num_planes);
+  DT_LAUNCH(cv_lowest_cost_kernel, grid, dim3(256), 0, to_stream(s), volume, params, depth_planes_bdhw, lowest, nhwc,
+            num_src, hw, num_planes);
   return check_launch("dt_cv_lowest_cost_f32");
 }
 
-int dt_cv_overall_mask_u8(const float* params, uint8_t* mask_out, int per_view, int batch, int num_src, int h, int w,
-                          int num_planes, dt_stream_t s) {
+int dt_cv_overall_mask_u8(const float* params, const float* depth_planes_bdhw, uint8_t* mask_out, int per_view, int batch,
+                          int num_src, int h, int w, int num_planes, dt_stream_t s) {
   DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0 && num_src > 0, "dt_cv_overall_mask_u8: bad extents");
   DT_REQUIRE(params && mask_out, "dt_cv_overall_mask_u8: null pointer");
   const size_t hw = (size_t)h * w;
   dim3 grid((unsigned)((hw + 255) / 256), batch);
-  DT_LAUNCH(cv_mask_kernel, grid, dim3(256), 0, to_stream(s), params, mask_out, per_view, num_src, h, w,
-                     num_planes);
+  DT_LAUNCH(cv_mask_kernel, grid, dim3(256), 0, to_stream(s), params, depth_planes_bdhw, mask_out, per_view, num_src, h, w,
+            num_planes);
   return check_launch("dt_cv_overall_mask_u8");
 }
 

@@ -12,9 +12,10 @@ fast path (utils/model_utils.py:30-35).  ``load_state_dict`` of a reference chec
 ``cost_volume.*`` keys works unchanged.
 
 Differences kept on purpose (SURVEY.md "facts" 6): geometry is derived from the input shape on
-every call, so any (h, w) works, landscape or portrait; ``depth_planes_bdhw`` overrides are
-accepted only when every plane is constant over the image (the only way the reference uses
-them).
+every call, so any (h, w) works, landscape or portrait.  Shapes outside the tuned kernels --
+``depth_planes_bdhw`` that vary over the image, ``matching_dim_size`` != 16 (<= 32), more than 15
+source views (<= 16) -- run on the general one-thread-per-sample HIP kernels (same results, not the
+tuned path; no released model uses them).
 
 There is no torch fallback: forward() raises if the tensors are not on a GPU or the HIP
 library cannot be loaded.
@@ -72,6 +73,7 @@ class CostVolumeManager(nn.Module):
         self.num_depth_bins = num_depth_bins
         self.matching_height = matching_height
         self.matching_width = matching_width
+        self._planes_px = None  # caller-supplied per-pixel planes of the call in flight (set by _setup)
         self.initialise_for_projection()
 
     # -- reference API ---------------------------------------------------------------------
@@ -183,33 +185,40 @@ class CostVolumeManager(nn.Module):
         params = torch.empty(b, pf, device=dev, dtype=torch.float32)
         _abi.check(L.dt_cv_setup_f32(_abi.ptr(Ks), _abi.ptr(ext), _abi.ptr(poses), _abi.ptr(invK), _abi.ptr(mn),
                                      _abi.ptr(mx), b, k, D, _abi.ptr(params), stream), "dt_cv_setup_f32")
+        planes_px = None
         if depth_planes_bdhw is not None:
             dp = depth_planes_bdhw
             if dp.shape[0] != b or dp.shape[1] != D:
                 raise ValueError("depth_planes_bdhw must be [b, num_depth_bins, h, w]")
             flat = dp.reshape(b, D, -1)
-            if not bool((flat == flat[:, :, :1]).all()):
-                raise NotImplementedError("per-pixel depth planes are not supported (the reference never uses them)")
-            params[:, 12:12 + D] = flat[:, :, 0].float()
+            if flat.shape[-1] == 1 or bool((flat == flat[:, :, :1]).all()):
+                params[:, 12:12 + D] = flat[:, :, 0].float()   # one depth per plane: the tuned kernels take it as is
+            elif flat.shape[-1] != h * w:
+                raise ValueError("depth_planes_bdhw must be [b, num_depth_bins, h, w]")
+            else:
+                # planes that vary over the image (cost_volume.py:249-250 takes any [b,D,h,w]): the general
+                # one-thread-per-sample kernels read the depth of every (plane, pixel) from this tensor
+                planes_px = _f32c(dp.to(dev)).view(b, D, h, w)
         src_nhwc = torch.empty(b, k, h, w, c, device=dev, dtype=torch.float32)
         _abi.check(L.dt_nchw_to_nhwc_f32(_abi.ptr(src), _abi.ptr(src_nhwc), b * k, c, h, w, stream),
                    "dt_nchw_to_nhwc_f32")
-        planes_bdhw = params[:, 12:12 + D].reshape(b, D, 1, 1).expand(b, D, h, w)
+        self._planes_px = planes_px
+        planes_bdhw = planes_px if planes_px is not None else params[:, 12:12 + D].reshape(b, D, 1, 1).expand(b, D, h, w)
         return L, stream, cur, src_nhwc, params, planes_bdhw, (b, k, c, h, w, D)
 
     def _lowest(self, L, stream, vol, params, nhwc, dims):
         b, k, c, h, w, D = dims
         low = torch.empty(b, h, w, device=vol.device, dtype=torch.float32)
-        _abi.check(L.dt_cv_lowest_cost_f32(_abi.ptr(vol), _abi.ptr(params), _abi.ptr(low), int(nhwc), b, k, h, w, D,
-                                           stream), "dt_cv_lowest_cost_f32")
+        _abi.check(L.dt_cv_lowest_cost_f32(_abi.ptr(vol), _abi.ptr(params), _abi.ptr(self._planes_px), _abi.ptr(low),
+                                           int(nhwc), b, k, h, w, D, stream), "dt_cv_lowest_cost_f32")
         return low
 
     def _mask(self, L, stream, params, per_view, dims):
         b, k, c, h, w, D = dims
         shape = (b, k, h, w) if per_view else (b, h, w)
         m = torch.empty(shape, device=params.device, dtype=torch.uint8)
-        _abi.check(L.dt_cv_overall_mask_u8(_abi.ptr(params), _abi.ptr(m), int(per_view), b, k, h, w, D, stream),
-                   "dt_cv_overall_mask_u8")
+        _abi.check(L.dt_cv_overall_mask_u8(_abi.ptr(params), _abi.ptr(self._planes_px), _abi.ptr(m), int(per_view), b, k,
+                                           h, w, D, stream), "dt_cv_overall_mask_u8")
         return m.view(torch.bool)  # bytes are 0/1: reinterpret, no copy kernel
 
     # -- forward -------------------------------------------------------------------------------
@@ -232,7 +241,11 @@ class CostVolumeManager(nn.Module):
         if hook is not None:
             hook("dot_begin")
         impl = CostVolumeManager._dot_impl
-        if impl == "lds":      # source footprint of each pixel tile staged in LDS (csrc/cv_dot_lds.hip)
+        if c != 16 or self._planes_px is not None:
+            # shapes outside the tuned kernel (matching_feature_dims != 16, per-pixel planes): general kernel
+            _abi.check(L.dt_cv_dot_simple_f32(_abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(self._planes_px),
+                                              _abi.ptr(vol), b, k, c, h, w, D, stream), "dt_cv_dot_simple_f32")
+        elif impl == "lds":      # source footprint of each pixel tile staged in LDS (csrc/cv_dot_lds.hip)
             _abi.check(L.dt_cv_dot_f32(_abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(vol), b, k, c, h, w, D,
                                        stream), "dt_cv_dot_f32")
         elif impl == "direct":  # every tap from global memory: same expressions, bit-identical (tests, ablation)
@@ -259,6 +272,8 @@ class FeatureVolumeManager(CostVolumeManager):
     #: it to record HIP events on the launch stream (roofline timing)
     _event_hook = None
     #: source views the fused MFMA kernel handles (84 KB of layer-1 weights per 7 views stay in LDS)
+    #: feature channels the general kernel takes (the fused kernel is built for the reference default, 16: options.py:127-136)
+    MAX_GENERAL_CHANNELS = 32
     MAX_FUSED_VIEWS = 15       # fused MFMA kernel: <= 7 views fully LDS-resident, 8..15 with the further views streamed from L2
     MAX_SPLIT16_VIEWS = 7      # the opt-in split-precision kernel keeps every view resident
     _warned_views = False
@@ -271,10 +286,13 @@ class FeatureVolumeManager(CostVolumeManager):
                  num_source_views=7):
         super().__init__(matching_height, matching_width, num_depth_bins)
         mlp_channels = list(mlp_channels) if mlp_channels is not None else [202, 128, 128, 1]
-        if matching_dim_size != 16:
-            raise NotImplementedError("matching_dim_size must be 16 (reference default, options.py:127-136)")
+        if not 1 <= int(matching_dim_size) <= self.MAX_GENERAL_CHANNELS:
+            raise ValueError(f"matching_dim_size={matching_dim_size} not in 1..{self.MAX_GENERAL_CHANNELS}")
+        self.matching_dim_size = int(matching_dim_size)
         self.num_source_views = num_source_views
-        mlp_channels[0] = mlp_pack.Columns(num_source_views).total  # feature_volume.py:49-67
+        # feature_volume.py:49-67: visual (1+K)*C + depth (1+K) + rays 3(1+K) + angle K + mask K + dot K + pose 3K
+        mlp_channels[0] = (self.matching_dim_size + 4) * (num_source_views + 1) + 6 * num_source_views
+        assert self.matching_dim_size != 16 or mlp_channels[0] == mlp_pack.Columns(num_source_views).total
         if mlp_channels[1:] != [128, 128, 1]:
             raise NotImplementedError("the fused kernel implements the reference's [Cin,128,128,1] matching MLP")
         self.mlp = MLP(channel_list=mlp_channels, disable_final_activation=True)
@@ -296,12 +314,12 @@ class FeatureVolumeManager(CostVolumeManager):
             return self._pack_cache["val"]
         arrs = [a.float().cpu().numpy() for a in self._mlp_arrays(self.mlp)]
         val = {}
-        if self.num_source_views <= self.MAX_FUSED_VIEWS:
+        if self.num_source_views <= self.MAX_FUSED_VIEWS and self.matching_dim_size == 16:
             packed = mlp_pack.pack_mlp(*arrs, self.num_source_views)
             val = {n: torch.from_numpy(v).to(device) for n, v in packed.items()}
         raw = self._mlp_arrays(self.mlp)
         val["raw"] = [_f32c(a.to(device)) for a in raw]
-        if self.num_source_views <= self.MAX_SPLIT16_VIEWS and self.precision == "split16":
+        if self.num_source_views <= self.MAX_SPLIT16_VIEWS and self.precision == "split16" and self.matching_dim_size == 16:
             sp = mlp_pack.pack_mlp_split(*arrs, self.num_source_views)
             for n in ("w1dyn", "w1pix", "w2"):
                 val["sp_" + n] = torch.from_numpy(sp[n].view(np.int16).copy()).to(device)
@@ -330,9 +348,13 @@ class FeatureVolumeManager(CostVolumeManager):
         b, k, c, h, w, D = dims
         if k != self.num_source_views:
             raise ValueError(f"built for {self.num_source_views} source views, got {k}")
-        if c != 16:
-            raise ValueError("matching features must have 16 channels")
+        if c != self.matching_dim_size:
+            raise ValueError(f"built for {self.matching_dim_size}-channel matching features, got {c}")
         dev = cur.device
+        if (c != 16 or self._planes_px is not None) and _impl == "mfma":
+            # matching_dim_size != 16 / planes that vary over the image: the reference accepts both
+            # (mesh_hint_volume.py:32,95), no released model uses them -- general kernel, not the tuned path
+            _impl = "simple"
         if k > self.MAX_FUSED_VIEWS and _impl == "mfma":
             # the fused MFMA kernel takes up to 15 source views (the reference's default is 7; the views beyond the seventh
             # stream their layer-1 weights from L2); more run on the general kernel -- correct, but not the tuned path
@@ -378,9 +400,9 @@ class FeatureVolumeManager(CostVolumeManager):
         elif _impl == "simple":
             r = pk["raw"]
             _abi.check(L.dt_cv_mlp_hint_simple_f32(
-                _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), *[_abi.ptr(t) for t in r], _abi.ptr(hint_ptr),
-                _abi.ptr(hd), _abi.ptr(hw_), _abi.ptr(hm), H2, W2, _abi.ptr(vol), b, k, h, w, D, stream),
-                "dt_cv_mlp_hint_simple_f32")
+                _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(self._planes_px), *[_abi.ptr(t) for t in r],
+                _abi.ptr(hint_ptr), _abi.ptr(hd), _abi.ptr(hw_), _abi.ptr(hm), H2, W2, _abi.ptr(vol), b, k, c, h, w, D,
+                stream), "dt_cv_mlp_hint_simple_f32")
         else:
             raise ValueError(_impl)
         _graphs.cut("mlp_end")
@@ -397,7 +419,7 @@ class FeatureVolumeManager(CostVolumeManager):
         manager shares the weights and differs only in the (reference-defined) mask semantics."""
         fast_cls = FastFeatureMeshHintVolumeManager if self._has_hint else FastFeatureVolumeManager
         m = fast_cls(self.matching_height, self.matching_width, num_depth_bins=self.num_depth_bins,
-                     num_source_views=self.num_source_views)
+                     matching_dim_size=self.matching_dim_size, num_source_views=self.num_source_views)
         m.mlp = self.mlp
         if self._has_hint:
             m.hint_mlp = self.hint_mlp

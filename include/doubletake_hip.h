@@ -124,28 +124,42 @@ int dt_cv_mlp_hint_split_f32(const float* cur_feats_bchw, const float* src_feats
                              int num_src, int h, int w, int num_planes, dt_stream_t s);
 
 /* Same function, one thread per (pixel, plane), plain fp32 FMAs, nn.Linear weight layouts
- * (W1 [128,Cin], b1, W2 [128,128], b2, W3 [1,128], b3).  GPU-side cross-check used by the
- * parity tests to localise failures; not used by the product modules. */
+ * (W1 [128,Cin], b1, W2 [128,128], b2, W3 [1,128], b3; Cin = (channels + 4)(num_src + 1) + 6 num_src,
+ * modules/feature_volume.py:49-67).  GPU-side cross-check of the fused kernel in the parity tests, and the
+ * product path for the shapes the fused kernel does not take: matching_dim_size != 16 (channels <= 32), more
+ * than 15 source views (<= 16), and caller-supplied per-pixel depth planes -- depth_planes_bdhw [b,D,h,w] or
+ * null (modules/mesh_hint_volume.py:95,149-150,211: "optionally, provide a depth plane to use instead of
+ * constructing one here"). */
 int dt_cv_mlp_hint_simple_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc,
-                              const float* params, const float* W1, const float* b1,
-                              const float* W2, const float* b2, const float* W3,
+                              const float* params, const float* depth_planes_bdhw, const float* W1,
+                              const float* b1, const float* W2, const float* b2, const float* W3,
                               const float* b3, const float* hint_mlp,
                               const float* depth_hint_b1HW, const float* hint_weights_b1HW,
                               const float* hint_mask_b1HW, int hint_h, int hint_w,
-                              float* volume_bdhw, int batch, int num_src, int h, int w,
+                              float* volume_bdhw, int batch, int num_src, int channels, int h, int w,
                               int num_planes, dt_stream_t s);
 
+/* CostVolumeManager.build_cost_volume (modules/cost_volume.py:219-315) one thread per (pixel, plane): any
+ * channel count, depth_planes_bdhw [b,D,h,w] or null (:249-250).  dt_cv_dot_f32 is the tuned kernel for
+ * 16 channels and one plane list per batch element. */
+int dt_cv_dot_simple_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc, const float* params,
+                         const float* depth_planes_bdhw, float* volume_bdhw, int batch, int num_src,
+                         int channels, int h, int w, int num_planes, dt_stream_t s);
+
 /* replaces: argmax + gather in CostVolumeManager.forward (modules/cost_volume.py:355-361).
- * volume may be NCHW (nhwc = 0) or NHWC (nhwc = 1); first maximum wins. */
-int dt_cv_lowest_cost_f32(const float* volume, const float* params, float* lowest_bhw,
-                          int nhwc, int batch, int num_src, int h, int w, int num_planes,
-                          dt_stream_t s);
+ * volume may be NCHW (nhwc = 0) or NHWC (nhwc = 1); first maximum wins.  The returned depth is
+ * depth_planes_bdhw's entry at the pixel when that tensor is given (indices_to_disparity's gather, :317-320),
+ * the parameter block's plane list otherwise. */
+int dt_cv_lowest_cost_f32(const float* volume, const float* params, const float* depth_planes_bdhw,
+                          float* lowest_bhw, int nhwc, int batch, int num_src, int h, int w,
+                          int num_planes, dt_stream_t s);
 
 /* replaces: get_mask + depth mask at the LAST plane (modules/cost_volume.py:73-94,
  * modules/mesh_hint_volume.py:270-287 [per_view = 1 -> uint8 [b,k,h,w]] and :818-822
- * [per_view = 0 -> uint8 [b,h,w]]). */
-int dt_cv_overall_mask_u8(const float* params, uint8_t* mask_out, int per_view, int batch,
-                          int num_src, int h, int w, int num_planes, dt_stream_t s);
+ * [per_view = 0 -> uint8 [b,h,w]]); depth_planes_bdhw as above. */
+int dt_cv_overall_mask_u8(const float* params, const float* depth_planes_bdhw, uint8_t* mask_out,
+                          int per_view, int batch, int num_src, int h, int w, int num_planes,
+                          dt_stream_t s);
 
 /* ---- conv stacks (cost-volume encoder / depth decoders) --------------------------------
  * One implicit-GEMM primitive on NHWC fp32 tensors (fp32 MFMA):

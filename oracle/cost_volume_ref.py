@@ -98,14 +98,15 @@ def grid_sample_bilinear_zeros(src_Bchw, u_BN, v_BN, h, w):
 
 
 def warp_features(src_feats_bkchw, src_ext_bk44, src_Ks_bk44, cur_invK_b44, plane_b):
-    """modules/cost_volume.py:132-217 for a single depth plane (same value at every pixel).
+    """modules/cost_volume.py:132-217 for a single depth plane: plane_b is [b] (one depth per batch element, what
+    generate_depth_planes yields) or [b, h*w] (a slice of a caller-supplied depth_planes_bdhw, :249-250).
 
     Returns world_points [b*k,4,N], depths [b,k,N] (z'), warped [b,k,c,N], mask [b,k,N],
     pix [b,k,2,N].
     """
     b, k, c, h, w = src_feats_bkchw.shape
     N = h * w
-    depth_bN = np.broadcast_to(np.asarray(plane_b, dtype=F32).reshape(b, 1), (b, N))
+    depth_bN = np.broadcast_to(np.asarray(plane_b, dtype=F32).reshape(b, -1), (b, N))
     world_b4N = backproject(depth_bN, cur_invK_b44, h, w)
     world_B4N = np.repeat(world_b4N, k, axis=0)
     cam = project(world_B4N, src_Ks_bk44.reshape(-1, 4, 4), src_ext_bk44.reshape(-1, 4, 4))
@@ -121,10 +122,18 @@ def warp_features(src_feats_bkchw, src_ext_bk44, src_Ks_bk44, cur_invK_b44, plan
     )
 
 
-def dot_cost_volume(cur_feats, src_feats, src_ext, src_Ks, cur_invK, min_depth, max_depth, num_bins):
+def _plane_list(min_depth, max_depth, num_bins, planes_bdhw, b, N):
+    """planes [b, D] from generate_depth_planes, or the caller's depth_planes_bdhw flattened to [b, D, N]
+    (modules/cost_volume.py:249-250: `if depth_planes_bdhw is None: ... generate_depth_planes`)."""
+    if planes_bdhw is None:
+        return generate_depth_planes(min_depth, max_depth, num_bins)
+    return np.asarray(planes_bdhw, dtype=F32).reshape(b, num_bins, N)
+
+
+def dot_cost_volume(cur_feats, src_feats, src_ext, src_Ks, cur_invK, min_depth, max_depth, num_bins, planes_bdhw=None):
     """CostVolumeManager.build_cost_volume, modules/cost_volume.py:219-315 -> [b, D, h, w]."""
     b, k, c, h, w = src_feats.shape
-    planes = generate_depth_planes(min_depth, max_depth, num_bins)
+    planes = _plane_list(min_depth, max_depth, num_bins, planes_bdhw, b, h * w)
     cur = cur_feats.reshape(b, 1, c, h * w)
     out = np.zeros((b, num_bins, h * w), dtype=F32)
     for d in range(num_bins):
@@ -135,10 +144,12 @@ def dot_cost_volume(cur_feats, src_feats, src_ext, src_Ks, cur_invK, min_depth, 
 
 
 def lowest_cost(volume_bdhw, planes_bd):
-    """modules/cost_volume.py:317-320,355-361: plane depth at argmax over d (first max)."""
+    """modules/cost_volume.py:317-320,355-361: plane depth at argmax over d (first max); planes_bd is [b, D] or
+    [b, D, h*w] / [b, D, h, w] (per-pixel planes: the gather of indices_to_disparity)."""
     idx = np.argmax(volume_bdhw, axis=1)
-    b = volume_bdhw.shape[0]
-    return np.take_along_axis(planes_bd.reshape(b, -1, 1, 1), idx[:, None], axis=1)[:, 0].astype(F32)
+    b, D, h, w = volume_bdhw.shape
+    planes = np.broadcast_to(np.asarray(planes_bd, dtype=F32).reshape(b, D, -1), (b, D, h * w)).reshape(b, D, h, w)
+    return np.take_along_axis(planes, idx[:, None], axis=1)[:, 0].astype(F32)
 
 
 def pose_distance(pose_B44):
@@ -214,7 +225,7 @@ def mlp_input_features(cur_feats, src_feats, src_ext, src_poses, src_Ks, cur_inv
     dot = ((warped * cur).sum(2, dtype=F32) * mask).astype(F32)  # :334-340
     pd, Rm, tm = pose_distance(src_poses.reshape(-1, 4, 4))  # :153-175
     ones = np.ones((1, 1, N), dtype=F32)
-    plane_map = np.broadcast_to(np.asarray(plane_b, dtype=F32).reshape(b, 1, 1), (b, 1, N))
+    plane_map = np.broadcast_to(np.asarray(plane_b, dtype=F32).reshape(b, 1, -1), (b, 1, N))
     feats = np.concatenate(
         [
             warped.reshape(b, k * c, N),
@@ -237,7 +248,7 @@ def mlp_input_features(cur_feats, src_feats, src_ext, src_poses, src_Ks, cur_inv
 
 def feature_volume(
     cur_feats, src_feats, src_ext, src_poses, src_Ks, cur_invK, min_depth, max_depth, num_bins, mlp_weights,
-    hint=None, hint_mlp_weights=None, return_mask=None,
+    hint=None, hint_mlp_weights=None, return_mask=None, planes_bdhw=None,
 ):
     """FeatureVolumeManager.build_cost_volume (modules/feature_volume.py:81-356) when
     hint is None, FeatureMeshHintVolumeManager.build_cost_volume
@@ -246,11 +257,12 @@ def feature_volume(
     hint = dict(depth_hint_b1hw, sampled_weights_b1hw, depth_hint_mask_b1hw) at (H2, W2).
     return_mask: None | "slow" (per-view mask of the LAST plane, :270-287) | "fast"
     (any_k depth AND any_k bounds at the last plane, :818-822).
-    Returns (volume [b,D,h,w], planes [b,D], mask or None).
+    planes_bdhw: the optional depth_planes_bdhw argument (:95,149-150), any [b,D,h,w].
+    Returns (volume [b,D,h,w], planes [b,D] -- [b,D,h*w] when planes_bdhw is given --, mask or None).
     """
     b, k, c, h, w = src_feats.shape
     N = h * w
-    planes = generate_depth_planes(min_depth, max_depth, num_bins)
+    planes = _plane_list(min_depth, max_depth, num_bins, planes_bdhw, b, N)
     if hint is not None:
         hd = nearest_resize(hint["depth_hint_b1hw"], h, w).reshape(b, N)
         hw_ = nearest_resize(hint["sampled_weights_b1hw"], h, w).reshape(b, N).astype(F32).copy()
@@ -263,7 +275,7 @@ def feature_volume(
         s = mlp_forward(feats.reshape(b * N, -1), mlp_weights).reshape(b, N)
         if hint is not None:
             with np.errstate(invalid="ignore"):
-                hmap = np.abs(hd - planes[:, d].reshape(b, 1)).astype(F32)  # :213
+                hmap = np.abs(hd - planes[:, d].reshape(b, -1)).astype(F32)  # :213
             hmap = np.where(hm, hmap, F32(-1.0)).astype(F32)  # :214
             hin = np.stack([s, hmap, hw_], -1).reshape(b * N, 3)
             s = mlp_forward(hin, hint_mlp_weights).reshape(b, N)  # :373-386

@@ -226,6 +226,74 @@ def gen_volume(ref, out):
         print(f"volume_{name}: slow-vs-fast max diff {np.abs(res['hint_volume'] - res['hint_volume_fast']).max():.2e}")
 
 
+def pixel_planes(b, D, h, w, min_depth, max_depth, seed):
+    """Depth planes that vary over the image (the optional depth_planes_bdhw argument of the volume managers): the
+    log-spaced list scaled by a smooth per-pixel factor in [0.8, 1.25] and a little noise; stored in the fixture."""
+    from doubletake_amd.utils import synthetic as syn
+
+    ramp = np.linspace(0, 1, D, dtype=np.float32).reshape(1, D, 1, 1)
+    mn = np.asarray(min_depth, np.float32).reshape(-1, 1, 1, 1)
+    mx = np.asarray(max_depth, np.float32).reshape(-1, 1, 1, 1)
+    base = np.exp(np.log(mn) + np.log(mx / mn) * ramp).astype(np.float32)
+    ys = np.linspace(-1, 1, h, dtype=np.float32).reshape(1, 1, h, 1)
+    xs = np.linspace(-1, 1, w, dtype=np.float32).reshape(1, 1, 1, w)
+    jitter = syn.hash_u01((b, D, h, w), seed).astype(np.float32)
+    scale = np.exp(np.float32(0.2) * (np.sin(np.float32(2.1) * xs + ramp) * np.cos(np.float32(1.7) * ys))) * (
+        np.float32(0.98) + np.float32(0.04) * jitter)
+    return np.ascontiguousarray(np.broadcast_to(base, (b, D, h, w)) * scale).astype(np.float32)
+
+
+def gen_volume_variants(ref, out):
+    """Shapes the tuned kernels do not take, run on the reference: per-pixel depth_planes_bdhw (16 channels) and
+    matching_dim_size = 8 / 24 -- dot, metadata-MLP and mesh-hint volumes (slow and fast managers)."""
+    import torch
+    from doubletake_amd.utils import synthetic as syn
+
+    cases = {
+        # name: (b, k, h, w, D, C, seed, per-pixel planes, behind_view)
+        "pp_k3": (1, 3, 24, 32, 8, 16, 21, True, False),
+        "pp_k2_b2": (2, 2, 19, 27, 5, 16, 22, True, True),
+        "c8_k2": (1, 2, 24, 32, 8, 8, 23, False, False),
+        "c24_k3_pp": (1, 3, 20, 28, 6, 24, 24, True, False),
+    }
+    res = {}
+    for name, (b, k, h, w, D, C, seed, pp, behind) in cases.items():
+        inp = syn.volume_inputs(b, k, h, w, C, seed, behind_view=behind)
+        ti = {n: t(v) for n, v in inp.items()}
+        hint = {n: ti[n] for n in ("depth_hint_b1hw", "depth_hint_mask_b1hw", "sampled_weights_b1hw")}
+        common = dict(cur_feats=ti["cur_feats"], src_feats=ti["src_feats"], src_extrinsics=ti["src_extrinsics"],
+                      src_poses=ti["src_poses"], src_Ks=ti["src_Ks"], cur_invK=ti["cur_invK"], min_depth=ti["min_depth"],
+                      max_depth=ti["max_depth"])
+        if pp:
+            res[f"{name}/planes_bdhw"] = pixel_planes(b, D, h, w, inp["min_depth"], inp["max_depth"], 900 + seed)
+            common["depth_planes_bdhw"] = t(res[f"{name}/planes_bdhw"])
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            cv = ref["cost_volume"].CostVolumeManager(h, w, num_depth_bins=D)
+            vol, low, planes, _ = cv(**common)
+            res[f"{name}/dot_volume"], res[f"{name}/dot_lowest"] = vol.numpy(), low.numpy()
+            fv = ref["feature_volume"].FeatureVolumeManager(
+                h, w, num_depth_bins=D, mlp_channels=[202, 128, 128, 1], matching_dim_size=C, num_source_views=k)
+            set_formula_weights(fv.mlp, 11 + seed, scale_mult=1.0)
+            vol, low, _, m = fv(**common, return_mask=True)
+            res[f"{name}/mlp_volume"], res[f"{name}/mlp_lowest"], res[f"{name}/mlp_mask"] = vol.numpy(), low.numpy(), m.numpy()
+            hv = ref["mesh_hint_volume"].FeatureMeshHintVolumeManager(
+                h, w, num_depth_bins=D, mlp_channels=[202, 128, 128, 1], matching_dim_size=C, num_source_views=k)
+            set_formula_weights(hv.mlp, 11 + seed, scale_mult=1.0)
+            set_formula_weights(hv.hint_mlp, 77 + seed, scale_mult=1.0)
+            vol, low, _, m = hv(**common, cv_depth_hint_dict={n: v.clone() for n, v in hint.items()}, return_mask=True)
+            res[f"{name}/hint_volume"], res[f"{name}/hint_lowest"] = vol.numpy(), low.numpy()
+            res[f"{name}/hint_mask_slow"] = m.numpy()
+            if C == 16:  # (the reference's to_fast() rebuilds the manager with the default 16 channels)
+                volf, lowf, _, mf = hv.to_fast()(
+                    **common, cv_depth_hint_dict={n: v.clone() for n, v in hint.items()}, return_mask=True)
+                res[f"{name}/hint_volume_fast"], res[f"{name}/hint_mask_fast"] = volf.numpy(), mf.numpy()
+        res[f"{name}/meta"] = np.array([b, k, h, w, D, C, seed, int(pp), int(behind)], dtype=np.int64)
+        print(f"volume_variants {name}: hint volume range {res[f'{name}/hint_volume'].min():.3f} .. "
+              f"{res[f'{name}/hint_volume'].max():.3f}, lowest {res[f'{name}/hint_lowest'].min():.3f} .. "
+              f"{res[f'{name}/hint_lowest'].max():.3f}")
+    np.savez_compressed(os.path.join(out, "volume_variants.npz"), **res)
+
+
 def gen_volume_fullsize(ref, out):
     """cfg1 / cfg2 full-size checksums."""
     import torch
@@ -525,10 +593,12 @@ def gen_formats(ref, out):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"volume", "fullsize", "networks", "model_fullsize", "tsdf", "formats"}
+    which = set(sys.argv[1:]) or {"volume", "variants", "fullsize", "networks", "model_fullsize", "tsdf", "formats"}
     ref = import_reference()
     if "volume" in which:
         gen_volume(ref, OUT)
+    if "variants" in which:
+        gen_volume_variants(ref, OUT)
     if "fullsize" in which:
         gen_volume_fullsize(ref, OUT)
     if "networks" in which:

@@ -106,6 +106,31 @@ def test_reference_shaped_forward_equals_forward_from_features():
         assert torch.equal(out[key], want[key]), key
 
 
+def test_model_with_other_matching_feature_dims_runs_on_the_general_volume_kernel():
+    """opts.matching_feature_dims != 16 (sr_depth_model.py:200,207): matching encoder with 8 output channels + the general
+    volume kernel; the volume inside the model equals the module called alone (pinned on the reference in test_volume_gpu)."""
+    import gpu_util as gu
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
+    from doubletake_amd.utils.rendering_utils import empty_hint
+
+    dev = gu.dev()
+    H, W, k, D, b = 128, 160, 2, 8, 1
+    m = DepthModelCVHint(H, W, depth_decoder_name="skip", matching_num_depth_bins=D, model_num_views=k + 1, matching_feature_dims=8)
+    gu.set_formula_weights(m, 11)
+    m.encoder = TinyImageEncoder()
+    gu.set_formula_weights(m.encoder, 12)
+    m = m.to(dev).eval()
+    assert m.cost_volume.matching_dim_size == 8 and m.cost_volume.mlp.net[0].in_features == syn.mlp_in_channels(k, 8)
+    cur, src = _batch(0, b, k, H, W, dev, _cams(b, H // 2, W // 2))
+    empty_hint(cur, torch.zeros(b, 1, H // 2, W // 2, device=dev))
+    out = m("test", cur, src, return_mask=True)
+    m_cur, m_src = m.compute_matching_feats(cur["image_b3hw"], src["image_b3hw"])
+    assert tuple(m_cur.shape) == (b, 8, H // 4, W // 4) and tuple(m_src.shape) == (b, k, 8, H // 4, W // 4)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(out[f"depth_pred_s{i}_b1hw"]).all() for i in range(4))
+    assert float(out["depth_pred_s0_b1hw"].std()) > 0
+
+
 def test_offline_two_pass_on_one_gpu():
     import gpu_util as gu
     from doubletake_amd import loops, parallel

@@ -76,3 +76,47 @@ def test_mlp_and_hint_volume(case):
     vol2, _, m2 = ref.feature_volume(*args, hint=hint, hint_mlp_weights=hint_w, return_mask="fast")
     np.testing.assert_allclose(vol2, g["hint_volume_fast"], atol=2e-5, rtol=0)
     np.testing.assert_array_equal(m2, g["hint_mask_fast"])
+
+
+# ---- shapes outside the tuned kernels: per-pixel depth_planes_bdhw, matching_dim_size != 16 -------------------------
+VARIANTS = ["pp_k3", "pp_k2_b2", "c8_k2", "c24_k3_pp"]
+
+
+def variant_case(name):
+    """(fixture view, inputs, dims, planes_bdhw or None) of one case of tests/golden/volume_variants.npz."""
+    G = load_golden("volume_variants.npz")
+    g = {k.split("/", 1)[1]: v for k, v in G.items() if k.startswith(name + "/")}
+    b, k, h, w, D, C, seed, pp, behind = [int(v) for v in g["meta"]]
+    inp = syn.volume_inputs(b, k, h, w, C, seed, behind_view=bool(behind))
+    return g, inp, (b, k, h, w, D, C, seed), (g["planes_bdhw"] if pp else None)
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_variant_shapes_vs_reference(name):
+    g, inp, (b, k, h, w, D, C, seed), planes = variant_case(name)
+    # (given planes are gathered exactly; generated ones differ from torch's exp by an ulp, as in test_planes_and_projection)
+    same_depth = np.testing.assert_array_equal if planes is not None else (
+        lambda a, d: np.testing.assert_allclose(a, d, rtol=3e-6))
+    vol, used = ref.dot_cost_volume(inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_Ks"], inp["cur_invK"],
+                                    inp["min_depth"], inp["max_depth"], D, planes_bdhw=planes)
+    np.testing.assert_allclose(vol, g["dot_volume"], atol=3e-4, rtol=0)
+    same_depth(ref.lowest_cost(g["dot_volume"], used), g["dot_lowest"])
+    cin = syn.mlp_in_channels(k, C)
+    pair = lambda l: [(l[i], l[i + 1]) for i in range(0, len(l), 2)]
+    mlp_w = pair(syn.formula_params(syn.mlp_param_shapes([cin, 128, 128, 1]), 11 + seed))
+    hint_w = pair(syn.formula_params(syn.mlp_param_shapes([3, 12, 12, 1]), 77 + seed))
+    args = (inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"], inp["cur_invK"],
+            inp["min_depth"], inp["max_depth"], D, mlp_w)
+    vol, used, m = ref.feature_volume(*args, return_mask="fast", planes_bdhw=planes)
+    np.testing.assert_allclose(vol, g["mlp_volume"], atol=2e-5, rtol=0)
+    np.testing.assert_array_equal(m, g["mlp_mask"])
+    same_depth(ref.lowest_cost(g["mlp_volume"], used), g["mlp_lowest"])
+    hint = {n: inp[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
+    vol, used, m = ref.feature_volume(*args, hint=hint, hint_mlp_weights=hint_w, return_mask="slow", planes_bdhw=planes)
+    np.testing.assert_allclose(vol, g["hint_volume"], atol=2e-5, rtol=0)
+    np.testing.assert_array_equal(m, g["hint_mask_slow"])
+    same_depth(ref.lowest_cost(g["hint_volume"], used), g["hint_lowest"])
+    if "hint_volume_fast" in g:
+        vol2, _, m2 = ref.feature_volume(*args, hint=hint, hint_mlp_weights=hint_w, return_mask="fast", planes_bdhw=planes)
+        np.testing.assert_allclose(vol2, g["hint_volume_fast"], atol=2e-5, rtol=0)
+        np.testing.assert_array_equal(m2, g["hint_mask_fast"])

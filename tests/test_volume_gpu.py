@@ -347,3 +347,73 @@ def test_split_precision_volume_fullsize_vs_fp32_kernel_and_reference_checksums(
     d = (exact - split).abs()
     assert d.max().item() < 2e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
     _probe_check(split.contiguous().cpu().numpy(), "cfg2_hint", g, 2e-4)
+
+
+# ---- shapes outside the tuned kernels (general one-thread-per-sample kernels): reference-generated fixture -------------
+@pytest.mark.parametrize("name", ["pp_k3", "pp_k2_b2", "c8_k2", "c24_k3_pp"])
+def test_per_pixel_planes_and_other_channel_counts_vs_reference(name):
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import CostVolumeManager, FeatureMeshHintVolumeManager, FeatureVolumeManager
+    from test_oracle_volume import variant_case
+
+    g, inp, (b, k, h, w, D, C, seed), planes = variant_case(name)
+    t = gu.to_dev(inp)
+    args = gu.volume_call_args(t)
+    if planes is not None:
+        args["depth_planes_bdhw"] = torch.from_numpy(planes).to(gu.dev())
+
+    def lowest_ok(low, key):
+        if planes is not None:   # the gather of the given planes is exact wherever the argmax is unambiguous
+            vol = g[key + "_volume"]
+            top2 = np.sort(vol, 1)[:, -2:]
+            clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+            np.testing.assert_array_equal(low.cpu().numpy()[clear], g[key + "_lowest"][clear])
+            assert clear.mean() > 0.5   # (the behind-view case has large tied regions in the dot volume)
+        else:
+            np.testing.assert_allclose(low.cpu().numpy(), g[key + "_lowest"], rtol=3e-6)
+
+    m = CostVolumeManager(h, w, num_depth_bins=D).to(gu.dev())
+    vol, low, used, _ = m(**args)
+    np.testing.assert_allclose(vol.cpu().numpy(), g["dot_volume"], atol=5e-4, rtol=0)
+    if planes is not None:
+        np.testing.assert_array_equal(used.cpu().numpy(), planes)
+    if name != "c8_k2":   # (its dot volume has exact ties at the image border: zero rows)
+        lowest_ok(low, "dot")
+
+    fv = FeatureVolumeManager(h, w, num_depth_bins=D, matching_dim_size=C, num_source_views=k).to(gu.dev())
+    gu.load_formula_mlp(fv.mlp, [syn.mlp_in_channels(k, C), 128, 128, 1], 11 + seed)
+    vol, low, _, mask = fv(**args, return_mask=True)
+    assert np.abs(vol.cpu().numpy() - g["mlp_volume"]).max() < 5e-5
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["mlp_mask"])
+    lowest_ok(low, "mlp")
+
+    hv = FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, matching_dim_size=C, num_source_views=k).to(gu.dev())
+    gu.load_formula_mlp(hv.mlp, [syn.mlp_in_channels(k, C), 128, 128, 1], 11 + seed)
+    gu.load_formula_mlp(hv.hint_mlp, [3, 12, 12, 1], 77 + seed)
+    vol, low, _, mask = hv(**args, cv_depth_hint_dict=gu.hint_dict(t), return_mask=True)
+    assert np.abs(vol.cpu().numpy() - g["hint_volume"]).max() < 5e-5
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["hint_mask_slow"])
+    lowest_ok(low, "hint")
+    fast = hv.to_fast()
+    vol2, _, _, mask2 = fast(**args, cv_depth_hint_dict=gu.hint_dict(t), return_mask=True)
+    assert np.abs(vol2.cpu().numpy() - vol.cpu().numpy()).max() == 0
+    if "hint_mask_fast" in g:
+        assert np.abs(vol2.cpu().numpy() - g["hint_volume_fast"]).max() < 5e-5
+        np.testing.assert_array_equal(mask2.cpu().numpy(), g["hint_mask_fast"])
+    torch.cuda.synchronize()
+
+
+def test_uniform_plane_override_still_takes_the_tuned_kernel():
+    """depth_planes_bdhw that is constant over the image (what generate_depth_planes returns) stays on the fused kernel."""
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import FeatureMeshHintVolumeManager
+
+    g, inp, t, (b, k, h, w, D, seed) = _case("k7_land")
+    m = FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 11 + seed)
+    gu.load_formula_mlp(m.hint_mlp, [3, 12, 12, 1], 77 + seed)
+    planes = torch.from_numpy(g["planes"]).to(gu.dev()).view(b, D, 1, 1).expand(b, D, h, w).contiguous()
+    vol, low, used, _ = m(**gu.volume_call_args(t), cv_depth_hint_dict=gu.hint_dict(t), depth_planes_bdhw=planes)
+    torch.cuda.synchronize()
+    assert m._planes_px is None and vol.is_contiguous(memory_format=torch.channels_last)
+    assert np.abs(vol.cpu().numpy() - g["hint_volume"]).max() < 5e-5
