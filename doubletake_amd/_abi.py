@@ -108,6 +108,8 @@ SIGNATURES = {
     "dt_mc_workspace_bytes": (_L, [_I, _I, _I]),
     "dt_mc_count": (_I, [_P, _P, _I, _I, _I, _F, C.POINTER(_I), C.POINTER(_I), _P, _P, _P]),
     "dt_mc_generate": (_I, [_P, _P, _I, _I, _I, _F, C.POINTER(_I), C.POINTER(_I), _P, _P, _P, _P, _I, _P]),
+    "dt_mc_raster_depth_f32": (_I, [_P, _P, _I, _I, _I, _F, C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _F, _P, _P, _I, _I,
+                                    _P, _P, _P]),
 }
 
 

@@ -21,6 +21,7 @@
 //   generate: recompute the per-thread count, block-local scan in LDS, write vertices / faces / ids
 #include "common.hpp"
 #include "mc_tables.hpp"
+#include "raster_device.hpp"
 
 namespace dt {
 
@@ -212,6 +213,68 @@ __global__ __launch_bounds__(256) void mc_generate_kernel(const McArgs a, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused marching cubes -> depth render for the per-frame hint of the incremental mode (test_incremental.py:204-258:
+// tsdf.to_mesh_pytorch3d -> MeshRasterizer zbuf).  A depth render needs neither the merged vertex list nor any
+// triangle order, only every triangle once: each workgroup classifies its 256 cells, compacts the triangles it found
+// through LDS (so that 256 lanes rasterise 256 triangles, whichever cells they came from) and rasterises them into the
+// z-buffer with the same raster_triangle() the stand-alone renderer uses.  No vertex buffer, no global scan, no vertex
+// count on the host: the count -> scan -> host read -> generate -> raster sequence (5 launches + one synchronisation per
+// frame) becomes one launch the host never waits for.  Same triangles, same vertex arithmetic, order-independent
+// atomicMin: bit-identical to dt_mc_generate + dt_raster_soup_depth_f32.
+// ------------------------------------------------------------------------------------------------------------------
+struct McRasterArgs {
+  float ox, oy, oz, vs;
+  const float* cam_T_world;
+  const float* K;
+  int h, w;
+  uint32_t* zb;
+};
+
+__global__ __launch_bounds__(256) void mc_raster_kernel(const McArgs a, const McRasterArgs r) {
+  __shared__ int lds[256];
+  __shared__ float cell_val[256][9];       // 8 corner values (+1 pad: lanes of a wave on different banks)
+  __shared__ int cell_ci[256];
+  __shared__ unsigned short tri_rec[256 * 5];  // (owner thread << 3) | triangle index within the cell
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int i = 0, j = 0, k = 0, ci = 0;
+  float val[8];
+  const int ntri = classify(a, id, i, j, k, ci, val) / 3;
+  if (__syncthreads_or(ntri) == 0) return;   // (most workgroups: no surface in their 256 cells)
+  int tot;
+  const int first = block_exclusive_scan(ntri, lds, tot);
+  if (ntri > 0) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cell_val[threadIdx.x][c] = val[c];
+    cell_ci[threadIdx.x] = ci;
+    for (int t = 0; t < ntri; ++t) tri_rec[first + t] = (unsigned short)((threadIdx.x << 3) | t);
+  }
+  __syncthreads();
+  const size_t base_id = (size_t)blockIdx.x * 256;
+  for (int q = threadIdx.x; q < tot; q += 256) {
+    const int rec = tri_rec[q];
+    const int owner = rec >> 3, t3 = (rec & 7) * 3;
+    const size_t oid = base_id + owner;
+    const int ok = (int)(oid % a.Z), oj = (int)((oid / a.Z) % a.Y), oi = (int)(oid / ((size_t)a.Z * a.Y));
+    const int oci = cell_ci[owner];
+    float X[3], Y[3], Z[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int e = kMcEdges[oci][t3 + v];
+      const int c1 = kEdgeCodes[e][0], c2 = kEdgeCodes[e][1];
+      const int x1 = ok + (c1 & 1), y1 = oj + ((c1 >> 1) & 1), z1 = oi + ((c1 >> 2) & 1);
+      const int x2 = ok + (c2 & 1), y2 = oj + ((c2 >> 1) & 1), z2 = oi + ((c2 >> 2) & 1);
+      float px, py, pz;   // (k, j, i) voxel-index coordinates, as dt_mc_generate writes them
+      vertex_interp(a.iso, (float)x1, (float)y1, (float)z1, (float)x2, (float)y2, (float)z2, cell_val[owner][c1],
+                    cell_val[owner][c2], px, py, pz);
+      X[v] = r.ox + pz * r.vs;   // world = origin + (i, j, k) * voxel_size (raster_soup_kernel)
+      Y[v] = r.oy + py * r.vs;
+      Z[v] = r.oz + px * r.vs;
+    }
+    raster_triangle(X, Y, Z, r.cam_T_world, r.K, r.h, r.w, r.zb);
+  }
+}
+
 static int fill(McArgs& a, const uint16_t* vol, const uint32_t* active, int X, int Y, int Z, float iso, const int* mn,
                 const int* mx, const char* who) {
   DT_REQUIRE(vol && active, "%s: null pointer", who);
@@ -268,6 +331,26 @@ int dt_mc_generate(const uint16_t* values, const uint32_t* active, int X, int Y,
   DT_LAUNCH(mc_generate_kernel, dim3((unsigned)nblocks), dim3(256), 0, to_stream(s), a,
                      reinterpret_cast<const int*>(workspace), verts, faces, ids, num_verts);
   return check_launch("dt_mc_generate");
+}
+
+int dt_mc_raster_depth_f32(const uint16_t* values, const uint32_t* active, int X, int Y, int Z, float isolevel, const int* mn,
+                           const int* mx, const float* origin3, float voxel_size, const float* cam_T_world_44,
+                           const float* K_44, int h, int w, uint32_t* workspace_hw, float* depth_hw, dt_stream_t s) {
+  McArgs a;
+  if (int rc = fill(a, values, active, X, Y, Z, isolevel, mn, mx, "dt_mc_raster_depth_f32")) return rc;
+  DT_REQUIRE(origin3 && cam_T_world_44 && K_44 && workspace_hw && depth_hw, "dt_mc_raster_depth_f32: null pointer");
+  DT_REQUIRE(h > 0 && w > 0 && voxel_size > 0.f, "dt_mc_raster_depth_f32: bad extents");
+  const size_t nblocks = (size_t)X * Y * Z / 256;
+  DT_REQUIRE(nblocks < 2147483647ull, "dt_mc_raster_depth_f32: volume too large");
+  McRasterArgs r;
+  r.ox = origin3[0]; r.oy = origin3[1]; r.oz = origin3[2]; r.vs = voxel_size;
+  r.cam_T_world = cam_T_world_44; r.K = K_44; r.h = h; r.w = w; r.zb = workspace_hw;
+  const int64_t n = (int64_t)h * w;
+  hipStream_t st = to_stream(s);
+  DT_LAUNCH(raster_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, n);
+  DT_LAUNCH(mc_raster_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, a, r);
+  DT_LAUNCH(raster_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace_hw, depth_hw, n);
+  return check_launch("dt_mc_raster_depth_f32");
 }
 
 }  // extern "C"

@@ -82,29 +82,41 @@ def prepare_mesh_hint(fuser, mesh_renderer, cur_data, render_height, render_widt
 
 
 @torch.no_grad()
-def prepare_mesh_hint_fused(fuser, cur_data, render_height, render_width, weight_threshold=0.025):
-    """Same outputs as prepare_mesh_hint in four kernels and no intermediate mesh object: marching-cubes
-    triangle soup -> depth render -> back-projection + weight sampling + threshold.  The rendered image can
-    differ from prepare_mesh_hint's in isolated pixels (vertices are not merged by edge id, so a shared vertex
-    may come from either neighbouring cell's interpolation: <= 1 ulp apart)."""
+def prepare_mesh_hint_fused(fuser, cur_data, render_height, render_width, weight_threshold=0.025, via_soup=False):
+    """Same outputs as prepare_mesh_hint without an intermediate mesh object and without a host read: marching cubes
+    fused with the depth render (dt_mc_raster_depth_f32: z-buffer init, one kernel that compacts each workgroup's
+    triangles in LDS and rasterises them, resolve) -> back-projection + weight sampling + threshold.  The rendered image
+    can differ from prepare_mesh_hint's in isolated pixels (vertices are not merged by edge id, so a shared vertex may
+    come from either neighbouring cell's interpolation: <= 1 ulp apart).
+    via_soup=True: the round-2 sequence (count -> scan -> host read of the vertex count -> generate -> raster), kept for
+    the bit-equality test of the two."""
     import ctypes as C
-
-    from .pytorch3d_extras import marching_cubes_raw
 
     L = _abi.lib()
     tsdf = fuser.tsdf_fuser_pred.tsdf
     dev = tsdf.device
     stream = _abi.current_stream(dev)
-    verts, _, _ = marching_cubes_raw(tsdf.tsdf_values, tsdf.voxel_bitmap, 0.0)
-    nf = int(verts.shape[0]) // 3
     h, w = render_height, render_width
     o = (C.c_float * 3)(*[float(v) for v in tsdf.origin.float().tolist()])
     T = cur_data["cam_T_world_b44"][0].to(device=dev, dtype=torch.float32).contiguous()
     K = cur_data["K_s0_b44"][0].to(device=dev, dtype=torch.float32).contiguous()
     depth = torch.empty(1, 1, h, w, device=dev, dtype=torch.float32)
     ws = torch.empty(h * w, device=dev, dtype=torch.int32)
-    _abi.check(L.dt_raster_soup_depth_f32(_abi.ptr(verts), nf, o, float(tsdf.voxel_size), _abi.ptr(T), _abi.ptr(K), h, w,
-                                          _abi.ptr(ws), _abi.ptr(depth), stream), "dt_raster_soup_depth_f32")
+    if via_soup:
+        from .pytorch3d_extras import marching_cubes_raw
+
+        verts, _, _ = marching_cubes_raw(tsdf.tsdf_values, tsdf.voxel_bitmap, 0.0)
+        nf = int(verts.shape[0]) // 3
+        _abi.check(L.dt_raster_soup_depth_f32(_abi.ptr(verts), nf, o, float(tsdf.voxel_size), _abi.ptr(T), _abi.ptr(K), h, w,
+                                              _abi.ptr(ws), _abi.ptr(depth), stream), "dt_raster_soup_depth_f32")
+    else:
+        vol = tsdf.tsdf_values
+        if vol.dtype != torch.float16 or not vol.is_contiguous():
+            vol = vol.half().contiguous()
+        X, Y, Z = vol.shape
+        _abi.check(L.dt_mc_raster_depth_f32(_abi.ptr(vol), _abi.ptr(tsdf.voxel_bitmap), X, Y, Z, 0.0, None, None, o,
+                                            float(tsdf.voxel_size), _abi.ptr(T), _abi.ptr(K), h, w, _abi.ptr(ws),
+                                            _abi.ptr(depth), stream), "dt_mc_raster_depth_f32")
     invK = cur_data["invK_s0_b44"][0].to(device=dev, dtype=torch.float32).contiguous()
     pose = cur_data["world_T_cam_b44"][0].to(device=dev, dtype=torch.float32).contiguous()
     hint = torch.empty_like(depth)

@@ -379,6 +379,16 @@ int dt_raster_depth_f32(const float* verts_v3, const int64_t* faces_f3, int64_t 
 int dt_raster_soup_depth_f32(const float* verts_kji_v3, int64_t num_faces, const float* origin3,
                              float voxel_size, const float* cam_T_world_44, const float* K_44, int h, int w,
                              uint32_t* workspace_hw, float* depth_hw, dt_stream_t s);
+/* Marching cubes and the depth render of its surface in ONE pass, for the per-frame hint of the incremental mode
+ * (test_incremental.py:204-258: tsdf.to_mesh_pytorch3d + PyTorch3DMeshDepthRenderer.render): every workgroup
+ * compacts the triangles of its 256 cells in LDS and rasterises them straight into the z-buffer.  No vertex buffer
+ * and no vertex count on the host (dt_mc_count's one host read per frame); depth_hw is bit-identical to
+ * dt_mc_count + dt_mc_generate + dt_raster_soup_depth_f32.  Arguments as in those calls. */
+int dt_mc_raster_depth_f32(const uint16_t* values_f16, const uint32_t* active, int X, int Y, int Z,
+                           float isolevel, const int* min_bounds3, const int* max_bounds3,
+                           const float* origin3, float voxel_size, const float* cam_T_world_44,
+                           const float* K_44, int h, int w, uint32_t* workspace_hw, float* depth_hw,
+                           dt_stream_t s);
 /* Hint maps from a rendered depth in one pass (test_incremental.py:204-258): back-project pixel centres
  * with invK / world_T_cam (device, 16 floats each, row-major 4x4), trilinearly sample the fused
  * weight volume, keep depth where rendered (!= -1) and weight >= threshold.  Outputs [h,w]:
