@@ -41,6 +41,11 @@ sys.path.insert(0, REPO)
 CONFIGS = {
     "cfg2_small": dict(image_h=480, image_w=640, num_src=7, planes=64, batch=1, decoder="skip", encoder="resnet18d",
                        what="DoubleTake-small, 640x480, 7 source views, 64 planes, batch=1 per GPU (BASELINE.json configs[1])"),
+    "cfg2_small_b2": dict(image_h=480, image_w=640, num_src=7, planes=64, batch=2, decoder="skip", encoder="resnet18d",
+                          what="DoubleTake-small, 640x480, 7 source views, 64 planes, batch=2 per GPU (side figure: what pairing "
+                               "keyframes per launch returns over two streams of batch-1 launches; not the headline config)"),
+    "cfg2_small_b4": dict(image_h=480, image_w=640, num_src=7, planes=64, batch=4, decoder="skip", encoder="resnet18d",
+                          what="DoubleTake-small, 640x480, 7 source views, 64 planes, batch=4 per GPU (side figure)"),
     "cfg2_full": dict(image_h=480, image_w=640, num_src=7, planes=64, batch=1, decoder="unet_pp", encoder="efficientnet",
                       what="DoubleTake full model (DepthDecoderPP), 640x480, 7 source views, 64 planes, batch=1 per GPU"),
     "cfg3_full_b8": dict(image_h=384, image_w=512, num_src=7, planes=64, batch=8, decoder="unet_pp", encoder="efficientnet",
