@@ -107,12 +107,16 @@ __device__ __forceinline__ int pixel_offset(bool inside, int n, int iy, int ix, 
 //   8  : one block per 512-thread workgroup, 8-way K split (the 30x40 level)
 //   16 : one block per 1024-thread workgroup, 16-way K split (only the low-resolution 1x1 downsample convs:
 //        for the 3x3 layers of the 15x20 level it measured 10 % slower than 8)
+#ifndef DT_CONV_S2_SWZ
+#define DT_CONV_S2_SWZ 1  // 0 = the pixel-major patch layout of the stride-2 bodies (A/B of the bank-conflict fix)
+#endif
 template <int KS, int ST, int SPLIT>
 struct ConvMfmaCfg {
   static constexpr int NW = (SPLIT >= 8) ? SPLIT : 4;
   static constexpr int IH = (kPH - 1) * ST + KS, IW = (kPW - 1) * ST + KS;
   static constexpr int NPIX = IH * IW;
-  static constexpr int PATCH_FLOATS = (ST == 1) ? 2 * IH * 12 * 4 : NPIX * 8;  // (stride 1: padded row pitch, see the body)
+  // (padded row pitch 12 and, for stride 2, one plane per column parity: see the body)
+  static constexpr int PATCH_FLOATS = (ST == 1) ? 2 * IH * 12 * 4 : (DT_CONV_S2_SWZ ? 2 * 2 * IH * 12 * 4 : NPIX * 8);
   static constexpr int TILE_FLOATS = (SPLIT == 1) ? PATCH_FLOATS : ((PATCH_FLOATS > 1024) ? PATCH_FLOATS : 1024);
   static constexpr int LDS_FLOATS = NW * TILE_FLOATS;
   static constexpr int THREADS = NW * 64;
@@ -161,13 +165,31 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
   // ds_read_b128 cycle services together ({0-3,12-15,20-27} / {4-11,16-19,28-31} of each half-wave) own pixel rows
   // {0,2} / {1,3} of the 4x8 block, so the 16 lanes of an access touch 16 different four-bank groups (12*row + col mod
   // 16).  The [pixel][8 channels] layout it replaces left SQ_LDS_BANK_CONFLICT at 63 % of this kernel's LDS cycles
-  // (profiles/r2i_pmc_summary.json).  Stride 2 keeps the pixel-major layout.
+  // (profiles/r2i_pmc_summary.json).
+  // Stride 2: a lane reads column 2*px + kx, so the pixel-major layout put the 16 lanes of an access on 4 bank groups
+  // (68*py + 4*px mod 16: SQ_LDS_BANK_CONFLICT = 50 % of the stride-2 kernels' LDS cycles, profiles/r3u_pmc_summary.json).
+  // Layout [channel half][column parity][row][column / 2, pitch 12][4 floats] with the natural lane -> pixel map: the
+  // bank group of a read is 24*py + px + const = 8*py + px (mod 16), and the lanes serviced together -- rows (0, px 0-3),
+  // (1, 4-7), (2, 4-7), (3, 0-3) or the complement -- cover all 16 groups.  The staging side enumerates a patch row as
+  // its even columns followed by its odd columns, so that the eight pixels x two halves of a store cycle are
+  // consecutive within one parity plane.
   constexpr bool SWZ = (ST == 1);
   constexpr int PITCH = 12;
   const bool grp_a = (p < 4) || (p >= 12 && p < 16) || (p >= 20 && p < 28);
   const int gi = grp_a ? ((p < 4) ? p : ((p < 16) ? p - 8 : p - 12)) : ((p < 12) ? p - 4 : ((p < 20) ? p - 8 : p - 16));
   const int py = SWZ ? 2 * (gi >> 3) + (grp_a ? 0 : 1) : (p >> 3), px = SWZ ? (gi & 7) : (p & 7);
-  auto lds_off = [&](int hf, int row, int col) { return SWZ ? ((hf * IH + row) * PITCH + col) * 4 : (row * IW + col) * 8 + hf * 4; };
+  constexpr bool SWZ2 = (ST == 2) && DT_CONV_S2_SWZ;
+  auto lds_off = [&](int hf, int row, int col) {
+    return SWZ ? ((hf * IH + row) * PITCH + col) * 4
+               : (SWZ2 ? ((((hf * 2 + (col & 1)) * IH + row) * PITCH) + (col >> 1)) * 4 : (row * IW + col) * 8 + hf * 4);
+  };
+  // staged pixel idx -> (row, column) of the patch
+  constexpr int NEVEN = (IW + 1) / 2;
+  auto patch_row = [&](int idx) { return idx / IW; };
+  auto patch_col = [&](int idx) {
+    const int r = idx - (idx / IW) * IW;
+    return SWZ2 ? ((r < NEVEN) ? 2 * r : 2 * (r - NEVEN) + 1) : r;
+  };
 
   const long total_blocks = (long)a.n * a.tiles_y * a.tiles_x * a.co_blocks;
   // cross-workgroup K split: workgroups [0, kplain) own a whole block each, the others share the remaining blocks P ways;
@@ -221,7 +243,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
 #pragma unroll
   for (int it = 0; it < NLOAD; ++it) {
     const int idx = (lane >> 1) + it * 32;
-    const int ly = idx / IW, lx = idx - ly * IW;
+    const int ly = patch_row(idx), lx = patch_col(idx);
     int iy = iy0 + ly, ix = ix0 + lx;
     bool inside = idx < NPIX && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
     if (a.pad_replicate) {
@@ -270,7 +292,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* __restr
     __builtin_amdgcn_wave_barrier();                                                                 \
     _Pragma("unroll") for (int it = 0; it < NLOAD; ++it) {                                           \
       const int idx = (lane >> 1) + it * 32;                                                         \
-      if (idx < NPIX) *reinterpret_cast<float4*>(tile + lds_off(lane & 1, idx / IW, idx % IW)) = patch[it]; \
+      if (idx < NPIX) *reinterpret_cast<float4*>(tile + lds_off(lane & 1, patch_row(idx), patch_col(idx))) = patch[it]; \
     }                                                                                                \
     if ((G) + g_step < a.groups) {                                                                   \
       DT_PREFETCH_PATCH((G) + g_step);                                                               \
