@@ -328,7 +328,7 @@ class _HotPathDepthModel(nn.Module):
                   return_mask=return_mask)
         if isinstance(self.cost_volume, FeatureMeshHintVolumeManager):  # the other managers take no hints
             kw["cv_depth_hint_dict"] = cv_depth_hint_dict
-        cost_volume, lowest_cost, _, overall_mask = self.cost_volume(**kw)
+        cost_volume, lowest_cost, overall_mask = self.volume_stage(kw)
         _graphs.cut("after_volume")  # (graph mode: the replay is split here so that the hook below runs between the halves)
         hook = None if torch.cuda.is_current_stream_capturing() else self.__dict__.pop("after_volume", None)
         if hook is not None:
@@ -336,6 +336,20 @@ class _HotPathDepthModel(nn.Module):
             # and all of its LDS) and beside the conv stack that follows (latency-bound, most of the chip idle):
             # loops.matching_lookahead encodes the next frame's keyframe here
             hook()
+        return self.network_stage(cur_feats, cost_volume, lowest_cost, overall_mask)
+
+    # The two halves of the forward pass, callable on their own so that a driver with several keyframes in flight can order
+    # them across HIP streams (bench.py --schedule phased): the volume kernel owns every CU and all of its LDS, the conv
+    # stack that follows is a chain of latency-bound launches that several frames can share.
+    @torch.no_grad()
+    def volume_stage(self, volume_kwargs):
+        """cost volume + lowest cost + mask of one keyframe batch (kwargs of self.cost_volume)."""
+        cost_volume, lowest_cost, _, overall_mask = self.cost_volume(**volume_kwargs)
+        return cost_volume, lowest_cost, overall_mask
+
+    @torch.no_grad()
+    def network_stage(self, cur_feats, cost_volume, lowest_cost, overall_mask):
+        """CVEncoder + depth decoder + exp on the volume of volume_stage -> the reference's output dict."""
         cv_feats = self.cost_volume_net(cost_volume, cur_feats[self.matching_scale:])
         feats = list(cur_feats[: self.matching_scale]) + cv_feats
         if isinstance(self.depth_decoder, SkipDecoderRegression):
