@@ -179,7 +179,10 @@ class _HotPathDepthModel(nn.Module):
             if cache.token != token:
                 cache.clear()
                 cache.token = token
-            missing = [j for j, fid in enumerate(flat_ids) if fid not in cache]
+            # (entries this call needs are taken out of the cache BEFORE anything new goes in: with a capacity below
+            #  b * (1 + K) the insertions below could otherwise evict them)
+            have = {fid: cache.get(fid) for fid in dict.fromkeys(flat_ids) if fid in cache}
+            missing = [j for j, fid in enumerate(flat_ids) if fid not in have]
             first = {}
             for j in missing:  # the same new frame may appear twice in one batch
                 first.setdefault(flat_ids[j], j)
@@ -191,10 +194,11 @@ class _HotPathDepthModel(nn.Module):
                 imgs = pick(todo[0]).unsqueeze(0) if len(todo) == 1 else torch.stack([pick(j) for j in todo], 0)
                 new = self._encode(imgs)
                 for row, j in enumerate(todo):
+                    have[flat_ids[j]] = new[row]
                     cache.put(flat_ids[j], new[row])
             # the cached maps are gathered straight into the two tensors the volume takes (one stack for the source views,
             # none for the current view at batch 1) -- not stacked as one [b*(1+K)] tensor and sliced apart again
-            got = [cache.get(fid) for fid in flat_ids]
+            got = [have[fid] for fid in flat_ids]
             cur_f = got[0].unsqueeze(0) if b == 1 else torch.stack([got[i * m] for i in range(b)], 0)
             src_f = torch.stack([got[i * m + 1 + k] for i in range(b) for k in range(m - 1)], 0)
             return cur_f, src_f.view(b, m - 1, *src_f.shape[1:])

@@ -197,6 +197,13 @@ def test_model_matching_feats_and_cross_frame_cache():
     cache.capacity = 4
     cache.put("x", c_cur[0])
     assert len(cache) == 4 and "x" in cache
+    # a capacity below one call's b * (1 + K) frames: the call still gets every map (taken out before the insertions)
+    cache.clear()
+    cache.capacity = 3
+    s_cur, s_src = model.compute_matching_feats(cur, src2, cur_ids=cur_ids, src_ids=src_ids)
+    assert torch.equal(s_cur, c_cur) and torch.equal(s_src, c_src) and len(cache) == 3
+    t_cur, t_src = model.compute_matching_feats(cur, src2, cur_ids=cur_ids, src_ids=src_ids)   # partly cached now
+    assert (t_cur - c_cur).abs().max() < 1e-4 and (t_src - c_src).abs().max() < 1e-4
 
 
 @pytest.mark.gpu
