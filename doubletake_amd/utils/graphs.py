@@ -1,9 +1,10 @@
 """hipGraph replay of a fixed-shape call: capture once, replay with one host call.
 
 The hot path at batch 1 is a chain of ~50 short kernels per keyframe; launched eagerly from Python the HOST needs about
-1 ms per frame for them (ctypes call + tensor bookkeeping per launch), and the per-scan loops add more.  In the incremental
-mode -- where no second frame can hide it -- that made the loop host-bound (2.5 ms/frame of Python against 2.1 ms of GPU
-work, scripts/time_incremental.py).  A captured graph is replayed with a single hipGraphLaunch.
+1 ms per frame for them (ctypes call + tensor bookkeeping per launch; 1.4 ms for a whole frame of the incremental loop).  A
+captured graph is replayed with a single hipGraphLaunch (0.5 ms of host time per incremental frame).  Opt-in: on an idle host
+the eager loop is GPU-bound anyway and measured slightly FASTER than the replay (2.03 vs 2.12 ms per incremental frame,
+1.76 vs 1.79 ms per bench step: DESIGN.md 4.2, round 3) -- the replay is for deployments whose host is busy or slow.
 
 ``GraphedCallable(fn)`` wraps a function of tensors (positional / keyword arguments, nested in lists, tuples and dicts;
 non-tensor arguments are part of the signature).  For every distinct signature (shapes, dtypes, devices, constants) it
