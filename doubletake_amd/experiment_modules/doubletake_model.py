@@ -251,7 +251,15 @@ class _HotPathDepthModel(nn.Module):
         cur = torch.cuda.current_stream(dev)
         stream.wait_stream(cur)  # the images (and the weights) are ready on the caller's stream
         with torch.cuda.stream(stream):
-            new = self._encode(image_n3hw[todo])
+            # (slices / the tensor itself where possible: indexing with a Python list uploads an index tensor from
+            #  pageable host memory, which costs the host the better part of a millisecond per frame)
+            if len(todo) == 1:
+                imgs = image_n3hw[todo[0]:todo[0] + 1]
+            elif todo == list(range(n)):
+                imgs = image_n3hw
+            else:
+                imgs = torch.stack([image_n3hw[j] for j in todo], 0)
+            new = self._encode(imgs)
             ready = _abi.record_ready(dev)
         image_n3hw.record_stream(stream)
         for row, j in enumerate(todo):
