@@ -160,6 +160,8 @@ def test_linearity_in_last_layer_at_full_size():
     ("cfg5_portrait_D96", 2, 7, 128, 96, 96),    # BASELINE configs[4]: 3RScan rotated (portrait), 96 planes
     ("tiny_one_view_D5", 3, 1, 3, 5, 5),         # fewer pixels than one MFMA tile, one source view, D % 8 != 0
     ("ragged_D13", 1, 4, 7, 45, 13),             # partial tiles + partial store chunks
+    ("odd_50x70_b2", 2, 3, 50, 70, 8),           # >= 64 tiles whose 32 pixels wrap image rows: the column-strip tile order
+    ("odd_33x97", 1, 2, 33, 97, 16),             # ... with a last tile that is partly outside the image
 ])
 def test_other_baseline_configs_mfma_vs_simple_and_oracle_probes(name, b, k, h, w, D):
     """Larger BASELINE shapes: the fused MFMA kernel against the independent one-thread-per-pair GPU
