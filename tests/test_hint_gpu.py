@@ -218,3 +218,44 @@ def test_fused_marching_cubes_render_is_bitwise_the_soup_render():
     fuser = OurFuser(None, 0.04, 3.0, bounds=BD)
     c = {"K_s0_b44": k[:1], "invK_s0_b44": torch.linalg.inv(k[:1]), "cam_T_world_b44": t[:1], "world_T_cam_b44": torch.linalg.inv(t[:1])}
     assert (prepare_mesh_hint_fused(fuser, c, 120, 160) == -1).all()
+
+
+def test_fused_marching_cubes_render_on_a_noisy_volume_with_bounds():
+    """Stress: random TSDF values (up to five triangles in most cells, every workgroup's LDS compaction filled), a random
+    half of the voxels active, a sub-box given as min / max bounds -- fused kernel against count -> generate -> soup raster,
+    bit for bit, through the C ABI."""
+    import ctypes as C
+
+    import gpu_util as gu
+    from doubletake_amd import _abi
+    from doubletake_amd.utils.pytorch3d_extras import marching_cubes_raw
+
+    dev = gu.dev()
+    L = _abi.lib()
+    X, Y, Z = 40, 48, 32
+    vs, h, w = 0.05, 120, 160
+    stream = _abi.current_stream(dev)
+    vol = torch.from_numpy(syn.hash_u01((X, Y, Z), 91) * 1.6 - 0.8).to(dev).half().contiguous()
+    active_mask = torch.from_numpy(syn.hash_u01((X * Y * Z,), 92) > 0.5).to(dev)
+    words = active_mask.view(-1, 32).to(torch.int64)
+    words = (words << torch.arange(32, device=dev, dtype=torch.int64)).sum(1)   # bit i of a word = voxel 32 * word + i
+    bitmap = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+    o = (C.c_float * 3)(-1.0, -1.2, 0.5)
+    K = torch.tensor([[150.0, 0, 80, 0], [0, 150.0, 60, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device=dev)
+    T = torch.eye(4, device=dev)
+    T[:3, 3] = torch.tensor([0.0, 0.0, 0.6])
+    for mn, mx in ((None, None), ((5, 6, 3), (30, 40, 28))):
+        verts, _, _ = marching_cubes_raw(vol, bitmap, 0.0, mn, mx)
+        nf = int(verts.shape[0]) // 3
+        assert nf > 20000
+        ws = torch.empty(h * w, device=dev, dtype=torch.int32)
+        want = torch.empty(h, w, device=dev)
+        _abi.check(L.dt_raster_soup_depth_f32(_abi.ptr(verts), nf, o, vs, _abi.ptr(T), _abi.ptr(K), h, w, _abi.ptr(ws),
+                                              _abi.ptr(want), stream), "soup")
+        got = torch.empty(h, w, device=dev)
+        ib = lambda b: None if b is None else (C.c_int * 3)(*b)
+        _abi.check(L.dt_mc_raster_depth_f32(_abi.ptr(vol), _abi.ptr(bitmap), X, Y, Z, 0.0, ib(mn), ib(mx), o, vs, _abi.ptr(T),
+                                            _abi.ptr(K), h, w, _abi.ptr(ws), _abi.ptr(got), stream), "fused")
+        torch.cuda.synchronize()
+        assert (want > 0).float().mean() > 0.5
+        assert torch.equal(want.view(torch.int32), got.view(torch.int32))
