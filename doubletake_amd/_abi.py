@@ -113,6 +113,10 @@ SIGNATURES = {
 }
 
 
+# = DT_ABI_VERSION of include/doubletake_hip.h (tests/test_abi.py compares the two)
+ABI_VERSION = 103
+
+
 def lib():
     """Load (building first if the sources changed and hipcc is available) and return the CDLL."""
     global _lib
@@ -137,6 +141,11 @@ def lib():
     except Exception:
         pass
     L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    L.dt_version.restype = _I
+    got = L.dt_version()
+    if got != ABI_VERSION:  # e.g. a stale variant .so behind DOUBLETAKE_HIP_LIB: shifted arguments, not a clean error
+        raise DoubletakeHipError(f"{path}: ABI version {got}, these bindings are written against {ABI_VERSION} "
+                                 "(include/doubletake_hip.h: DT_ABI_VERSION) -- rebuild the library")
     ns = _Lib(L)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the symbol is missing: fail loudly

@@ -83,7 +83,7 @@ using namespace dt;
 
 extern "C" {
 
-int dt_version(void) { return 101; }
+int dt_version(void) { return DT_ABI_VERSION; }
 
 const char* dt_last_error(void) { return err_buf(); }
 

@@ -292,14 +292,17 @@ class _HotPathDepthModel(nn.Module):
         return self
 
     def _weights_token(self):
-        return tuple(p._version for m in (self.cost_volume, self.cost_volume_net, self.depth_decoder) for p in m.parameters())
+        # (data_ptr as well as the version counter: ``module.weight = nn.Parameter(...)`` or a swapped submodule brings a
+        # new tensor at an old version, and the captured launches carry the old packed-weight pointers)
+        return tuple((p.data_ptr(), p._version, str(p.device)) for m in (self.cost_volume, self.cost_volume_net, self.depth_decoder)
+                     for p in m.parameters())
 
     def _encode(self, images_n3hw):
         """Matching encoder pass; single images replay a captured graph when graphs are on (the incremental loop encodes
         exactly one new keyframe per frame)."""
         g = getattr(self, "_graphed_encoder", None)
         if g is not None and images_n3hw.shape[0] == 1:
-            token = tuple(p._version for p in self.matching_model.parameters())
+            token = tuple((p.data_ptr(), p._version, str(p.device)) for p in self.matching_model.parameters())
             if getattr(self, "_encoder_token", token) != token:
                 g.reset()
             self._encoder_token = token
@@ -341,8 +344,11 @@ class _HotPathDepthModel(nn.Module):
         if isinstance(self.cost_volume, FeatureMeshHintVolumeManager):  # the other managers take no hints
             kw["cv_depth_hint_dict"] = cv_depth_hint_dict
         cost_volume, lowest_cost, overall_mask = self.volume_stage(kw)
-        _graphs.cut("after_volume")  # (graph mode: the replay is split here so that the hook below runs between the halves)
-        hook = None if torch.cuda.is_current_stream_capturing() else self.__dict__.pop("after_volume", None)
+        # graph mode: the replay is split here so that the hook below runs between the halves -- only when a hook is
+        # waiting at capture time (every cut is one more hipGraphLaunch per replay)
+        if "after_volume" in self.__dict__:
+            _graphs.cut("after_volume")
+        hook = None if (torch.cuda.is_current_stream_capturing() or _graphs.in_warmup()) else self.__dict__.pop("after_volume", None)
         if hook is not None:
             # one-shot: work for the caller to enqueue on ANOTHER stream behind the volume kernel (which fills every CU
             # and all of its LDS) and beside the conv stack that follows (latency-bound, most of the chip idle):

@@ -158,6 +158,7 @@ def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fu
             empty_hint(cur_data, torch.zeros(1, 1, H2, W2, device=ref.device, dtype=torch.float32))
             if timer is not None:
                 timer.skip("hint_time")
+        owner = None
         if lookahead is not None and nxt is not None:
             owner = getattr(lookahead, "after_volume_of", None)
             if owner is not None:
@@ -166,7 +167,14 @@ def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fu
                 lookahead(*nxt)
         if timer is not None:
             timer.start("model_time")
-        outputs = model_fn(cur_data, src_data)
+        try:
+            outputs = model_fn(cur_data, src_data)
+        finally:
+            # the one-shot hook belongs to THIS frame: if model_fn raised or never went through the owner's forward, a
+            # stale closure over the next batch must not fire on a later, unrelated forward
+            stale = None if owner is None else owner.__dict__.pop("after_volume", None)
+        if stale is not None:
+            stale()  # (model_fn did not consume it: run the lookahead now, as without an owner)
         if timer is not None:
             timer.stop("model_time")
         depth = _depth_for_fusion(outputs, fuse_size, mask_pred_depth, per_view_mask=True)

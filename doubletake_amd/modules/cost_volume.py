@@ -384,7 +384,9 @@ class FeatureVolumeManager(CostVolumeManager):
         else:
             vol = torch.empty(b, D, h, w, device=dev, dtype=torch.float32)
         hook = FeatureVolumeManager._event_hook
-        _graphs.cut("mlp_begin")  # (hipGraph capture: segment boundary, see utils/graphs.py; a no-op otherwise)
+        if hook is not None:
+            _graphs.cut("mlp_begin")  # (hipGraph capture: segment boundary so that the hook's events bracket the kernel on
+            #                           replay too; without a hook no cut -- every cut is one more hipGraphLaunch per replay)
         if hook is not None and not torch.cuda.is_current_stream_capturing():
             hook("mlp_begin")
         if _impl == "mfma" and self.precision == "split16" and k <= self.MAX_SPLIT16_VIEWS:
@@ -405,7 +407,8 @@ class FeatureVolumeManager(CostVolumeManager):
                 stream), "dt_cv_mlp_hint_simple_f32")
         else:
             raise ValueError(_impl)
-        _graphs.cut("mlp_end")
+        if hook is not None:
+            _graphs.cut("mlp_end")
         if hook is not None and not torch.cuda.is_current_stream_capturing():
             hook("mlp_end")
         low = self._lowest(L, stream, vol, params, nhwc, dims)

@@ -17,6 +17,8 @@ signature.  One replay at a time per signature (the graph owns its intermediates
 stream).  No CPU fallback: capture needs a ROCm GPU."""
 from __future__ import annotations
 
+import threading
+
 import torch
 
 
@@ -44,15 +46,24 @@ def _rebuild(obj, tensors):
     return obj
 
 
-_CAPTURING = None  # the GraphedCallable whose capture is in progress on this thread (cut() talks to it)
+_TLS = threading.local()  # .capturing: the GraphedCallable whose capture is in progress on THIS thread (cut() talks to
+#                            it); .warming: True while its un-captured warm-up passes run
 
 
 def cut(tag=None):
     """Called by the wrapped function at a point where the replay should be split in two graphs, so that the owner can
     enqueue other work between them -- an event, or a launch on another stream: ``GraphedCallable(fn, between=...)``
-    receives ``tag`` after the segment that ends here.  A no-op outside a capture."""
-    if _CAPTURING is not None:
-        _CAPTURING._cut(tag)
+    receives ``tag`` after the segment that ends here.  A no-op outside a capture.  Every cut costs one more
+    hipGraphLaunch per replay: callers cut only where something is actually going to be enqueued."""
+    g = getattr(_TLS, "capturing", None)
+    if g is not None:
+        g._cut(tag)
+
+
+def in_warmup():
+    """True inside the warm-up passes a GraphedCallable runs before its capture (side stream, throw-away outputs): one-shot
+    hooks of the wrapped function must not be consumed there."""
+    return bool(getattr(_TLS, "warming", False))
 
 
 class GraphedCallable:
@@ -81,22 +92,25 @@ class GraphedCallable:
         s_args, s_kwargs = _rebuild((args, kwargs), iter(static))
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(self.warmup):
-                self.fn(*s_args, **s_kwargs)
-                # the second pass finds every weight-pack cache entry complete (their ready events have fired), so nothing
-                # in the captured pass has to look at an event recorded outside the capture
-                side.synchronize()
+        _TLS.warming = True
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):
+                    self.fn(*s_args, **s_kwargs)
+                    # the second pass finds every weight-pack cache entry complete (their ready events have fired), so
+                    # nothing in the captured pass has to look at an event recorded outside the capture
+                    side.synchronize()
+        finally:
+            _TLS.warming = False
         torch.cuda.current_stream(dev).wait_stream(side)
         # capture ON the warm-up stream: the library keeps its cross-workgroup reduction scratch per (device, stream) and
         # must not allocate while a stream is capturing
-        global _CAPTURING
         self._pool = torch.cuda.graph_pool_handle()
         self._segments = [torch.cuda.CUDAGraph()]
         self._tags = []
         side.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
-        _CAPTURING = self
+        _TLS.capturing = self
         try:
             with torch.cuda.stream(side):
                 self._segments[0].capture_begin(pool=self._pool)
@@ -105,7 +119,7 @@ class GraphedCallable:
                 finally:
                     self._segments[-1].capture_end()
         finally:
-            _CAPTURING = None
+            _TLS.capturing = None
         torch.cuda.current_stream(dev).wait_stream(side)
         segments, self._segments = self._segments, None
         self.captures += 1

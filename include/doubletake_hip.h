@@ -28,6 +28,11 @@ extern "C" {
 typedef void* dt_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------------------ */
+/* ABI version: bumped whenever the signature of ANY entry point below changes (not for new entry points alone).
+ * Bindings compare it with the version they were written against before the first call: an older .so called with
+ * shifted arguments would corrupt device memory instead of failing.  History: 101 round 2; 102 round 3 (depth_planes /
+ * channels arguments of dt_cv_lowest_cost_f32, dt_cv_overall_mask_u8, dt_cv_mlp_hint_simple_f32); 103 round 4. */
+#define DT_ABI_VERSION 103
 int dt_version(void);
 const char* dt_last_error(void);
 /* number of HIP devices visible; <0 on runtime error.  No other call needs it. */

@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"{s} declared in doubletake_hip.h but not exported"
     # and the Python binding table covers exactly the header
     assert sorted(_abi.SIGNATURES) == syms
-    assert L.dt_version() >= 100
+    # the ABI version the bindings were written against == the header's == what the built library reports
+    header_version = int(re.search(r"#define\s+DT_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert L.dt_version() == header_version == _abi.ABI_VERSION
 
 
 def test_argument_errors_are_reported_not_launched():
@@ -143,3 +145,51 @@ def test_model_selection_follows_reference_model_utils(tmp_path):
     torch.save({"state_dict": sd}, path)
     with pytest.raises(RuntimeError):
         mu.load_model_inference(o, DepthModelCVHint)
+
+
+def test_lightning_style_checkpoint_with_foreign_hyper_parameters_loads(tmp_path):
+    """reference checkpoints are Lightning files whose ``hyper_parameters`` hold a pickled
+    ``doubletake.options`` object (doubletake_model.py:116).  The loader must read ``state_dict`` from such a file
+    without the defining module being importable, and must not execute foreign reduce callables."""
+    import sys
+    import types
+
+    import torch
+
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
+    from doubletake_amd.utils import model_utils as mu
+
+    o = types.SimpleNamespace(model_type="cv_hint_depth_model", feature_volume_type="mlp_mesh_hint_feature_volume",
+                              image_height=64, image_width=96, model_num_views=3, matching_num_depth_bins=16,
+                              fast_cost_volume=False, load_weights_from_checkpoint=None)
+    src = DepthModelCVHint(o)
+    with torch.no_grad():
+        for i, p in enumerate(src.parameters()):
+            p.fill_(0.002 * (i + 1))
+    # a throw-away module standing in for doubletake.options; gone again before the file is read
+    mod = types.ModuleType("fake_doubletake_options")
+    exec("class Options:\n    def __init__(self):\n        self.image_height = 64\n        self.name = 'x'\n"
+         "def evil(*a):\n    raise SystemExit('reduce callable executed')\n"
+         "class Trap:\n    def __reduce__(self):\n        return (evil, (1,))\n", mod.__dict__)
+    sys.modules["fake_doubletake_options"] = mod
+    try:
+        path = tmp_path / "lightning.ckpt"
+        torch.save({"epoch": 3, "global_step": 10, "pytorch-lightning_version": "1.8.4",
+                    "state_dict": dict(src.state_dict()), "hyper_parameters": {"opts": mod.Options()},
+                    "callbacks": {"trap": mod.Trap()}, "optimizer_states": [{"state": {}, "param_groups": []}]}, path)
+    finally:
+        del sys.modules["fake_doubletake_options"]
+    with pytest.raises(Exception):  # the stock loader refuses the file (torch >= 2.6 defaults to weights_only=True)
+        torch.load(path, map_location="cpu")
+    state = mu.read_checkpoint_state_dict(path)
+    assert set(state) == set(src.state_dict())
+    o.load_weights_from_checkpoint = str(path)
+    got = mu.load_model_inference(o, DepthModelCVHint)
+    for (n1, a), (n2, b) in zip(src.state_dict().items(), got.state_dict().items()):
+        assert n1 == n2 and torch.equal(a, b)
+    # a plain state-dict file still loads; a file without tensors is rejected
+    torch.save(dict(src.state_dict()), tmp_path / "plain.pt")
+    assert set(mu.read_checkpoint_state_dict(tmp_path / "plain.pt")) == set(src.state_dict())
+    torch.save({"state_dict": {"a": 1}}, tmp_path / "bad.pt")
+    with pytest.raises(RuntimeError):
+        mu.read_checkpoint_state_dict(tmp_path / "bad.pt")
