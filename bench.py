@@ -264,6 +264,148 @@ def dot_volume_roofline(device, t, launches=30):
     }
 
 
+def _event_ms(fn, device, n, warm):
+    """Mean HIP-event time of n calls of fn() on the current stream after warm untimed calls."""
+    import torch
+
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(device)
+    evs = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream(device))
+        fn()
+        b.record(torch.cuda.current_stream(device))
+        evs.append((a, b))
+    torch.cuda.synchronize(device)
+    return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+
+def tsdf_roofline(device):
+    """TSDF integrate / sample / marching cubes against the HBM roofline, after the timed region.
+    Volumes of the drivers over the 8 x 8 x 3.2 m synthetic room: 0.04 m (hint volume, 200x200x80) and 0.02 m (final volume,
+    400x400x160: options.py fusion_resolution).  Algorithmic bytes: integrate = X*Y*Z*(2+2)*2 B (value and
+    weight, read + written) + 2*H*W B (the half depth map); sample = N * (12 B point + 8 corners * 2 B + 4 B result);
+    marching cubes = X*Y*Z * (2 B value + 1/8 B active bit) + 12 B per vertex + 24 B (int64 ids) per face.  The integrate
+    kernel only touches voxels inside the frame's frustum box, so its fraction by this formula can exceed what its own
+    counters show (profiles/): both are reported as defined."""
+    import torch
+    from doubletake_amd.tools.fusers_helper import OurFuser
+    from doubletake_amd.utils import synthetic as syn
+
+    room = dict(xmin=-4.0, xmax=4.0, ymin=-4.0, ymax=4.0, zmin=0.0, zmax=3.2)
+    H2, W2 = 240, 320
+    depth, K, T = syn.tsdf_frames(12, H2, W2, seed=5, bounds=room)
+    d, k, tt = (torch.from_numpy(a).to(device) for a in (depth, K, T))
+    out = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "room_m": [8.0, 8.0, 3.2], "depth_map": [H2, W2]}
+
+    def entry(ms, nbytes, **extra):
+        e = {"avg_launch_ms": ms, "algorithmic_bytes": nbytes, "achieved": nbytes / (ms * 1e-3) / 1e9,
+             "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0}
+        e.update(extra)
+        return e
+
+    for res in (0.04, 0.02):
+        f = OurFuser(None, res, 3.0, bounds=room)
+        X, Y, Z = (int(v) for v in f.tsdf_fuser_pred.tsdf.tsdf_values.shape)
+        state = {"i": 0}
+
+        def integrate():
+            i = state["i"] % 12
+            state["i"] += 1
+            f.fuse_frames(d[i:i + 1], k[i:i + 1], tt[i:i + 1], None)
+
+        ms = _event_ms(integrate, device, 12, 12)
+        tag = f"{res:.2f}m"
+        out[f"integrate_{tag}"] = entry(ms, 8.0 * X * Y * Z + 2.0 * H2 * W2, volume=[X, Y, Z],
+                                         kernels="tsdf_frame_setup + tsdf_integrate (one frame per call)")
+        # sample_tsdf: the 76 800 back-projected pixels of a fused frame (what the hint weights step samples)
+        Kn, Tn = K[0].astype(np.float64), T[0].astype(np.float64)
+        ys, xs = np.meshgrid(np.arange(H2), np.arange(W2), indexing="ij")
+        pix = np.stack([xs.ravel() + 0.0, ys.ravel() + 0.0, np.ones(H2 * W2)], 0)
+        cam = np.linalg.inv(Kn[:3, :3]) @ pix * depth[0].reshape(1, -1)
+        world = (np.linalg.inv(Tn) @ np.concatenate([cam, np.ones((1, cam.shape[1]))], 0))[:3].T
+        pts = torch.from_numpy(np.ascontiguousarray(world, dtype=np.float32)).to(device)
+        tsdf = f.tsdf_fuser_pred.tsdf
+        ms = _event_ms(lambda: tsdf.sample_tsdf(pts, what_to_sample="weights"), device, 20, 5)
+        out[f"sample_{tag}"] = entry(ms, pts.shape[0] * (12.0 + 16.0 + 4.0), points=int(pts.shape[0]), kernels="tsdf_sample")
+        # marching cubes (count -> scan -> generate; includes the host read of the two counts)
+        _, verts, faces = f.get_mesh_pytorch3d()
+        nv, nf = int(verts.shape[0]), int(faces.shape[0])
+        ms = _event_ms(lambda: f.get_mesh_pytorch3d(), device, 8, 2)
+        out[f"marching_cubes_{tag}"] = entry(ms, X * Y * Z * 2.125 + 12.0 * nv + 24.0 * nf, verts=nv, faces=nf,
+                                              kernels="mc_count + mc_scan + mc_generate (+ 8-byte host read)")
+        del f, tsdf
+        torch.cuda.empty_cache()
+    return out
+
+
+def end_to_end(device, t, pyr_t, model, frames=40):
+    """Frames/s of the reference entry point ``model("test", cur_data, src_data)`` INCLUDING the HIP matching encoder
+    (ResnetMatchingEncoder, reference modules/networks.py:138-189) on the 1 + K images of every keyframe -- the step just
+    before the volume that the headline (forward_from_features) leaves outside.  Image-prior encoder: out of scope (a
+    resident synthetic pyramid stands in).  Two modes: "cache_off" = all 1 + K images through the encoder every frame (the
+    reference's behaviour); "cache_on" = the cross-frame feature cache (only the new keyframe is encoded; sliding window of
+    sources as in a scan).  Wall clock over `frames` keyframes on one stream, no host synchronisation inside the loop."""
+    import torch
+    import torch.nn as nn
+    from doubletake_amd.utils import synthetic as syn
+
+    class FixedPyramid(nn.Module):
+        def __init__(self, pyr):
+            super().__init__()
+            self.pyr = pyr
+
+        def forward(self, image):
+            return self.pyr
+
+    if model.matching_model is None:
+        return None
+    H, W, k_src = CFG["image_h"], CFG["image_w"], CFG["num_src"]
+    prev_enc = model.encoder
+    model.encoder = FixedPyramid(pyr_t)
+    n = frames + 8
+    images = torch.from_numpy(syn.hash_normalish((n + k_src, 3, H, W), 77)).to(device)
+    Ks = torch.linalg.inv(t["cur_invK"])
+    eye = torch.eye(4, device=device).view(1, 4, 4)
+    data = []
+    for f in range(n):
+        cur = {"image_b3hw": images[f + k_src:f + k_src + 1], "frame_id_string": [f"{f + k_src:06d}"],
+               "K_s1_b44": Ks, "invK_s1_b44": t["cur_invK"], "cam_T_world_b44": eye, "world_T_cam_b44": eye}
+        src = {"image_b3hw": images[f:f + k_src].flip(0).unsqueeze(0).contiguous(),
+               "frame_id_string": [[f"{f + k_src - 1 - i:06d}"] for i in range(k_src)],
+               "K_s1_b44": t["src_Ks"], "cam_T_world_b44": t["src_extrinsics"], "world_T_cam_b44": t["src_poses"]}
+        data.append((cur, src))
+    hint = {nm: t[nm] for nm in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
+    res = {"entry_point": 'model("test", cur_data, src_data): matching encoder on 1+K images + volume + CVEncoder + decoder',
+           "frames": frames, "streams": 1}
+    prev_cache = getattr(model, "use_feature_cache", False)
+    try:
+        for mode, cache in (("cache_off", False), ("cache_on", True)):
+            model.matching_feature_cache.clear()
+            model.use_feature_cache = cache
+
+            def run(lo, hi):
+                for f in range(lo, hi):
+                    cur, src = data[f]
+                    cur = dict(cur, **hint)
+                    model("test", cur, dict(src), return_mask=True)
+
+            run(0, 8)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            run(8, n)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            res[mode] = {"frames_per_s": frames / dt, "ms_per_frame": dt / frames * 1e3}
+    finally:
+        model.use_feature_cache = prev_cache
+        model.encoder = prev_enc
+        model.matching_feature_cache.clear()
+    return res
+
+
 def self_launch(n):
     """Re-execute this script under torch.distributed.run with n ranks on this node (rendezvous on
     127.0.0.1, a free port).  The children's stdout is passed through unchanged, so the caller still
@@ -301,6 +443,8 @@ def main():
     ap.add_argument("--no-cpu-batched", dest="cpu_batched", action="store_false",
                     help="skip the one timing of the batched (Fast-manager) CPU volume (BASELINE.md section 3 asks for both variants)")
     ap.add_argument("--no-fuse", action="store_true", help="skip the TSDF integration of the gathered frames")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="skip the untimed side legs after the timed region (TSDF roofline, end-to-end with the matching encoder)")
     ap.add_argument("--mlp-precision", choices=("fp32", "split16"), default="fp32",
                     help="arithmetic of the matching-MLP contractions in the volume kernel: exact fp32 MFMA (default, the headline) "
                          "or the opt-in split-precision mode (fp16 hi/lo operands on the fp16 matrix pipe, fp32 accumulation)")
@@ -531,7 +675,7 @@ def main():
         frames = args.steps * CFG["batch"] * world
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the figure comes from
         # the last scripts/collect_pmc.sh pass -- and only while the kernel source it was measured on is the one built now
-        traffic, traffic_tag = None, None
+        traffic, traffic_tag, executed = None, None, None
         tf = os.path.join(REPO, "profiles", "roofline_traffic.json")
         if os.path.isfile(tf) and default_cfg and args.mlp_precision == "fp32":
             try:
@@ -542,6 +686,7 @@ def main():
                 if rec.get("kernel_source_sha16") == hashlib.sha256(src).hexdigest()[:16]:
                     traffic = rec.get("cv_mlp_mfma_kernel_hbm_bytes_per_launch")
                     traffic_tag = rec.get("profile_tag")
+                    executed = rec.get("executed_mfma_flops_per_launch")
             except Exception:
                 traffic = None
         result = {
@@ -584,6 +729,14 @@ def main():
                 "traffic_profile": traffic_tag,
                 "algorithmic_flops_per_launch": flops,
                 "avg_launch_ms": kern_ms,
+                # what the matrix pipe really executed (SQ_VALU_MFMA_BUSY_CYCLES / 64 x 4096 flop, same hash-checked PMC record
+                # as `traffic`): the kernel contracts the plane-invariant input columns once per pixel tile, so it executes
+                # fewer MFMAs than the algorithmic count.  mfma_busy_frac = executed flops / launch time / nominal peak = the
+                # share of the launch during which the matrix pipe holds an MFMA.  On gfx950 the fp32 MFMA and the fp32 vector
+                # instructions do not overlap (scripts/mfma_filler_bench.hip: every vector instruction beside the MFMAs costs
+                # 3-5.5 cycles of matrix time), so 1 - mfma_busy_frac is mostly the kernel's own vector work, not idle time
+                "executed_flops_per_launch": executed,
+                "mfma_busy_frac": (executed / (kern_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if executed else None,
             },
         }
         if conv_flops is not None and conv_ms == conv_ms:
@@ -603,8 +756,18 @@ def main():
         if single is not None:
             single["frac_of_mfma_peak_isolated"] = flops / (single["dominant_kernel_avg_launch_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
             result["single_stream"] = single
+        if use_dist:
+            # self-verifying multi-GPU line: how many ranks RCCL really connected, and which RCCL
+            result["config"]["ranks_seen"] = int(dist.get_world_size())
+            try:
+                result["config"]["rccl_version"] = ".".join(map(str, torch.cuda.nccl.version()))
+            except Exception:
+                result["config"]["rccl_version"] = None
         if world == 1 and default_cfg:
             result["roofline_warp_match_dot"] = dot_volume_roofline(device, t)
+            if not args.no_side_legs:
+                result["roofline_tsdf"] = tsdf_roofline(device)
+                result["end_to_end"] = end_to_end(device, t, pyr_t, model)
         if not default_cfg:
             result["cpu_baseline"] = None  # the CPU leg is defined on the default workload
         if world == 1 and default_cfg and not args.no_cpu_baseline:
