@@ -98,6 +98,8 @@ SIGNATURES = {
                                           C.POINTER(TsdfThresholds), _P]),
     "dt_tsdf_integrate_frames_f32depth_f16": (_I, [_P, _P, _P, C.POINTER(_F), _F, _I, _I, _I, _P, _I, _I, _I, _P,
                                                    C.POINTER(TsdfThresholds), _P]),
+    "dt_tsdf_integrate_frames_xslab_f16": (_I, [_P, _P, _P, C.POINTER(_F), _F, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P,
+                                                C.POINTER(TsdfThresholds), _P]),
     "dt_tsdf_sample_f16": (_I, [_P, C.POINTER(_F), _F, _I, _I, _I, _P, _P, _L, _I, _P]),
     "dt_sparse_block_voxels": (_I, []),
     "dt_sparse_integrate_f32": (_I, [_P, _P, _I, _F, _P, _P, _P, _P, _I, _P, _I, _I, C.POINTER(_F), C.POINTER(_F), _F, _F, _I, _P]),

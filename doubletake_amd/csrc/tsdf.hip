@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
                                                             uint32_t* __restrict__ active, int X, int Y, int Z,
                                                             const void* __restrict__ depth_any, int img_h, int img_w,
                                                             const float* __restrict__ fp_all, int num_frames,
-                                                            const TsdfConsts c) {
+                                                            const TsdfConsts c, int x_begin) {
   // num_frames frames are integrated IN ORDER per voxel (the update is order dependent through the half
   // running mean and the weight clamp, tools/tsdf.py:553-558); the voxel's value/weight stay in registers
   // between frames, rounded to half exactly where the reference stores them.
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
   // bitmap words stay wave-aligned), y = i.  A slab whose x coordinate lies outside every frame's
   // frustum box leaves after one scalar test -- on the default +-10 m volume that is most of the grid.
   const size_t total = (size_t)X * Y * Z;
-  const int i = blockIdx.y;
+  const int i = blockIdx.y + x_begin;  // (x_begin > 0: this launch integrates an x-slab [x_begin, x_begin + gridDim.y) only)
   const unsigned slab = (unsigned)Y * (unsigned)Z;
   const unsigned pidx = blockIdx.x * blockDim.x + threadIdx.x;
   const float cx = rh(c.origin[0] + (float)i * c.voxel_size);
@@ -348,7 +348,8 @@ int dt_tsdf_integrate_f16(uint16_t* values, uint16_t* weights, uint32_t* active,
 
 static int integrate_frames(uint16_t* values, uint16_t* weights, uint32_t* active, const float* origin3, float voxel_size, int X,
                             int Y, int Z, const void* depth, bool depth32, int num_frames, int img_h, int img_w,
-                            const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s) {
+                            const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s, int x_begin = 0,
+                            int x_count = -1) {
   DT_REQUIRE(values && weights && active && origin3 && depth && frame_params && th, "dt_tsdf_integrate_f16: null pointer");
   DT_REQUIRE(X > 0 && Y > 0 && Z > 0 && img_h > 0 && img_w > 0 && voxel_size > 0.f && num_frames > 0,
              "dt_tsdf_integrate_f16: bad extents");
@@ -371,13 +372,17 @@ static int integrate_frames(uint16_t* values, uint16_t* weights, uint32_t* activ
   const size_t slab = (size_t)Y * Z;
   DT_REQUIRE(slab % 64 == 0, "dt_tsdf_integrate_f16: Y*Z must be a multiple of 64 (dims are multiples of 8)");
   DT_REQUIRE(X <= 65535 && slab < 4294967040ull, "dt_tsdf_integrate_f16: volume too large for one launch");
-  const dim3 grid((unsigned)((slab + 255) / 256), (unsigned)X);
+  if (x_count < 0) x_count = X - x_begin;
+  DT_REQUIRE(x_begin >= 0 && x_count >= 0 && x_begin + x_count <= X, "dt_tsdf_integrate_f16: x-slab [%d, %d) outside 0..%d", x_begin,
+             x_begin + x_count, X);
+  if (x_count == 0) return 0;
+  const dim3 grid((unsigned)((slab + 255) / 256), (unsigned)x_count);
   if (depth32)
     DT_LAUNCH(tsdf_integrate_kernel<true>, grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, img_h,
-                       img_w, frame_params, num_frames, c);
+                       img_w, frame_params, num_frames, c, x_begin);
   else
     DT_LAUNCH(tsdf_integrate_kernel<false>, grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, img_h,
-                       img_w, frame_params, num_frames, c);
+                       img_w, frame_params, num_frames, c, x_begin);
   return check_launch("dt_tsdf_integrate_f16");
 }
 
@@ -393,6 +398,14 @@ int dt_tsdf_integrate_frames_f32depth_f16(uint16_t* values, uint16_t* weights, u
                                           int img_w, const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s) {
   return integrate_frames(values, weights, active, origin3, voxel_size, X, Y, Z, depth_f32, true, num_frames, img_h, img_w,
                           frame_params, th, s);
+}
+
+int dt_tsdf_integrate_frames_xslab_f16(uint16_t* values, uint16_t* weights, uint32_t* active, const float* origin3,
+                                       float voxel_size, int X, int Y, int Z, int x_begin, int x_count, const void* depth,
+                                       int depth_is_f32, int num_frames, int img_h, int img_w, const float* frame_params,
+                                       const dt_tsdf_thresholds* th, dt_stream_t s) {
+  return integrate_frames(values, weights, active, origin3, voxel_size, X, Y, Z, depth, depth_is_f32 != 0, num_frames, img_h,
+                          img_w, frame_params, th, s, x_begin, x_count);
 }
 
 int dt_tsdf_sample_f16(const uint16_t* volume, const float* origin3, float voxel_size, int X, int Y, int Z,

@@ -17,6 +17,15 @@ One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Three
   (``shard_scenes``: longest-processing-time by frame count).  No data-path collective; each finished
   scan's TSDF (values + weights, fp16, variable extent) goes to rank 0 with a size-then-padded
   all_gather (``gather_variable``) for export, in rounds so that the collectives match.
+* **voxel-slab fusion** (``KeyframeShardFuser(mode="slab")`` -- 8e row 3, the alternative for large final volumes).
+  The exchange is the same, but every rank integrates the gathered frames of ALL ranks into ITS x-slab of the volume
+  only (X/W planes of Y*Z voxels: contiguous in the [X,Y,Z] layout); one all_gather of the slabs (``gather_slabs``)
+  completes every replica before anything reads the volume (meshing, hint sampling, save_tsdf).  A voxel's update
+  depends on that voxel and the frame sequence alone, and voxel centres are computed from the GLOBAL index
+  (dt_tsdf_integrate_frames_xslab_f16), so the assembled volume is bit-identical to a serial run.  Replica fusion costs
+  every rank N*b full-volume passes per step -- the one term of the design that grows with the GPU count (16 x 205 MB at
+  cfg5's 0.02 m final volume on 8 GPUs); slab fusion keeps it at N*b/N passes' worth of voxels, for one 2*X*Y*Z*(2+2)/N
+  byte gather per rank at the end of the pass.
 * world == 1: nothing is exchanged and no packing kernel runs.
 
 Payload per rank and step of the keyframe shard: b*(h*w + 32) halves (ScanNet depth-res 240x320:
@@ -66,8 +75,34 @@ def exchange_updates(local: torch.Tensor, world: int, force_collective: bool = F
     return out
 
 
+def slab_bounds(X: int, world: int, rank: int):
+    """x-range [x0, x1) of rank's slab: ceil(X / world) planes per rank, the last ranks possibly short or empty."""
+    rows = (int(X) + world - 1) // world
+    return min(rank * rows, int(X)), min((rank + 1) * rows, int(X))
+
+
+def _slab_adapter(fuser):
+    """(set_slab(x0, x1), arrays() -> tensors whose first dimension is X) of a fuser.  The HIP ``OurFuser`` restricts its
+    integrate kernel through ``TSDFFuser.x_range``; test doubles bring their own ``set_slab`` / ``slab_arrays``."""
+    if hasattr(fuser, "set_slab") and hasattr(fuser, "slab_arrays"):
+        return fuser.set_slab, fuser.slab_arrays
+    tf = fuser.tsdf_fuser_pred
+    X = int(tf.tsdf.tsdf_values.shape[0])
+
+    def set_slab(x0, x1):
+        tf.x_range = (int(x0), int(x1))
+
+    def arrays():
+        t = tf.tsdf
+        return [t.tsdf_values, t.tsdf_weights, t.voxel_bitmap.view(X, -1)]  # (Y*Z is a multiple of 64: whole words per plane)
+
+    return set_slab, arrays
+
+
 class KeyframeShardFuser:
-    """Replica TSDF + per-step exchange.
+    """Replica TSDF + per-step exchange (``mode="replica"``), or voxel-slab fusion (``mode="slab"``: see the module text;
+    needs ``fuser`` -- the HIP ``OurFuser`` or an object with ``set_slab(x0, x1)`` / ``slab_arrays()``; call
+    ``gather_slabs()`` before the volume is read).
 
     ``fuse_fn(depth_n1hw, K_n44, T_n44)`` integrates n frames in the given order; by default it is
     ``fuser.fuse_frames`` of the HIP ``OurFuser`` passed as ``fuser``.  ``depth_hw`` is the size of the depth maps
@@ -76,7 +111,11 @@ class KeyframeShardFuser:
     only the predicted resolution crosses xGMI.
     """
 
-    def __init__(self, device, world, rank, depth_hw, fuser=None, fuse_fn=None, force_collective=False, upsample_to=None):
+    def __init__(self, device, world, rank, depth_hw, fuser=None, fuse_fn=None, force_collective=False, upsample_to=None,
+                 mode="replica"):
+        if mode not in ("replica", "slab"):
+            raise ValueError(f"mode {mode!r}: 'replica' or 'slab'")
+        self.mode = mode
         self.world, self.rank, self.device = int(world), int(rank), device
         self.force_collective = bool(force_collective)
         self.h, self.w = int(depth_hw[0]), int(depth_hw[1])
@@ -90,12 +129,46 @@ class KeyframeShardFuser:
         self._local = None
         self._all = None
         self.frames_fused = 0
+        self.slabs_current = True  # (slab mode: False between the first integration and the next gather_slabs())
+        if mode == "slab":
+            if fuser is None:
+                raise ValueError("slab mode needs the fuser whose volume is sharded")
+            self._set_slab, self._slab_arrays = _slab_adapter(fuser)
+            self._X = int(self._slab_arrays()[0].shape[0])
+            self.slab = slab_bounds(self._X, self.world, self.rank)
+            self._set_slab(*self.slab)
 
     def _fuse(self, depth, K, T):
         if self.upsample_to is not None and tuple(depth.shape[-2:]) != self.upsample_to:
             depth = F.interpolate(depth.float(), size=self.upsample_to, mode="nearest").to(depth.dtype)
         self.fuse_fn(depth, K, T)
         self.frames_fused += int(depth.shape[0])
+        if self.mode == "slab":
+            self.slabs_current = False
+
+    def gather_slabs(self):
+        """Slab mode: all_gather every rank's x-slab (values, weights, active bits) so that each replica holds the whole
+        volume again.  Collective: every rank must call it at the same point (the loops below do, at the end of a pass).
+        Integration may continue afterwards (the replica outside the own slab goes stale again until the next gather).
+        Returns the number of bytes this rank received."""
+        if self.mode != "slab":
+            return 0
+        collective = self.world > 1 or (self.force_collective and _collective_ready())
+        got = 0
+        if collective:
+            rows = (self._X + self.world - 1) // self.world
+            x0, x1 = self.slab
+            for a in self._slab_arrays():
+                send = torch.zeros((rows,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+                send[: x1 - x0].copy_(a[x0:x1])
+                out = torch.empty((self.world * rows,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+                # (as raw bytes: the payload is bit patterns -- half values, int32 bitmap words -- and byte tensors are the
+                #  one dtype every backend moves)
+                dist.all_gather_into_tensor(out.view(torch.uint8), send.view(torch.uint8))
+                a.copy_(out[: self._X])  # rank-major rows == x order; rows past X are the padding of a short last slab
+                got += out.numel() * out.element_size()
+        self.slabs_current = True
+        return got
 
     def exchange_and_fuse(self, depth_b1hw, K_b44, cam_T_world_b44, counts=None, rows=None):
         """One step.  ``depth_b1hw`` [b,1,h,w] with its cameras ([b,4,4] each, any float dtype; cast to half like
@@ -156,6 +229,7 @@ def run_sharded_pass(num_batches, batch_size_of, step_fn, shard_fuser: KeyframeS
         if mine < num_batches:
             depth, K, T = step_fn(mine)
         total += shard_fuser.exchange_and_fuse(depth, K, T, counts=counts, rows=rows)
+    shard_fuser.gather_slabs()  # (slab mode: complete every replica before anything reads the volume; no-op otherwise)
     return total
 
 

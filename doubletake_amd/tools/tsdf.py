@@ -254,6 +254,9 @@ class TSDFFuser:
         self.use_gpu = True
         self.truncation_size = 3.0
         self.maxW = 100.0
+        #: (x_begin, x_end) or None: restrict integrate_depth to this x-slab of the volume (multi-GPU voxel-slab fusion,
+        #: parallel.KeyframeShardFuser(mode="slab")); voxels outside are left untouched
+        self.x_range = None
         L = _abi.lib()
         self._fp_floats = int(L.dt_tsdf_frame_params_floats())
         self._frame_params = torch.empty(self._fp_floats, dtype=torch.float32, device=tsdf.device)
@@ -316,6 +319,13 @@ class TSDFFuser:
         _abi.check(L.dt_tsdf_frames_setup_f16(_abi.ptr(K16), _abi.ptr(T16), nf, img_h, img_w, float(np.float32(depth_min)),
                                               float(np.float32(depth_max)), _abi.ptr(self._frame_params), stream),
                    "dt_tsdf_frames_setup_f16")
+        if self.x_range is not None:
+            x0, x1 = int(self.x_range[0]), int(self.x_range[1])
+            _abi.check(L.dt_tsdf_integrate_frames_xslab_f16(
+                _abi.ptr(t.tsdf_values), _abi.ptr(t.tsdf_weights), _abi.ptr(t.voxel_bitmap), o, float(np.float32(t.voxel_size)),
+                X, Y, Z, x0, x1 - x0, _abi.ptr(depth), int(depth32), nf, img_h, img_w, _abi.ptr(self._frame_params), C.byref(th),
+                stream), "dt_tsdf_integrate_frames_xslab_f16")
+            return
         entry = L.dt_tsdf_integrate_frames_f32depth_f16 if depth32 else L.dt_tsdf_integrate_frames_f16
         _abi.check(entry(_abi.ptr(t.tsdf_values), _abi.ptr(t.tsdf_weights), _abi.ptr(t.voxel_bitmap), o,
                          float(np.float32(t.voxel_size)), X, Y, Z, _abi.ptr(depth), nf, img_h, img_w,

@@ -343,6 +343,15 @@ int dt_tsdf_integrate_frames_f32depth_f16(uint16_t* values, uint16_t* weights, u
                                           const float* origin3, float voxel_size, int X, int Y, int Z,
                                           const float* depth_f32, int num_frames, int img_h, int img_w,
                                           const float* frame_params, const dt_tsdf_thresholds* th, dt_stream_t s);
+/* Voxel-slab form for multi-GPU fusion of large final volumes (alternative): the same update
+ * restricted to the x-slab [x_begin, x_begin + x_count) of the FULL volume the pointers address -- voxel centres are
+ * computed from the global index, so a volume assembled from the slabs of several ranks is bit-identical to one
+ * integrated whole (tools/tsdf.py:414-558 per voxel).  depth: fp16 or (depth_is_f32) fp32 maps, as above. */
+int dt_tsdf_integrate_frames_xslab_f16(uint16_t* values, uint16_t* weights, uint32_t* active,
+                                       const float* origin3, float voxel_size, int X, int Y, int Z,
+                                       int x_begin, int x_count, const void* depth, int depth_is_f32,
+                                       int num_frames, int img_h, int img_w, const float* frame_params,
+                                       const dt_tsdf_thresholds* th, dt_stream_t s);
 /* replaces: TSDF.sample_tsdf (tools/tsdf.py:277-339), trilinear, align_corners=True, zeros
  * padding.  fp16_math = 0 reproduces the reference's CPU branch (fp32 math on the half volume,
  * pinned by goldens); 1 rounds grid and result to half like its GPU branch (unpinned).

@@ -125,3 +125,50 @@ def test_cfg5_size_two_pass_loop_through_the_collective_path():
         assert (a.tsdf_weights > 0).sum().item() > 5000
         assert torch.equal(a.tsdf_values.view(torch.int16), c.tsdf_values.view(torch.int16))
         assert torch.equal(a.tsdf_weights.view(torch.int16), c.tsdf_weights.view(torch.int16))
+
+
+def test_world1_rccl_slab_mode_at_the_final_volume_size():
+    """KeyframeShardFuser(mode="slab") through a real RCCL group (world 1, collective forced) at the
+    drivers' final-volume size (0.02 m over the 8 x 8 x 3.2 m room: 400 x 400 x 160, 205 MB per pass): exchange,
+    slab-restricted integrate, byte all_gather of values / weights / active bits -- equal to the serial fuse."""
+    import torch.distributed as dist
+
+    import gpu_util as gu
+    from doubletake_amd import parallel as par
+    from doubletake_amd.tools.fusers_helper import OurFuser
+
+    dev = gu.dev()
+    torch.cuda.set_device(dev)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    s.close()
+    os.environ.pop("NCCL_DEBUG", None)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        room = dict(xmin=-4.0, xmax=4.0, ymin=-4.0, ymax=4.0, zmin=0.0, zmax=3.2)
+        H, W = 240, 320
+        depth, K, T = syn.tsdf_frames(6, H, W, seed=5, bounds=room)
+        d, k, t = (torch.from_numpy(a).to(dev) for a in (depth, K, T))
+        serial = OurFuser(None, 0.02, 3.0, bounds=room)
+        slab = OurFuser(None, 0.02, 3.0, bounds=room)
+        assert tuple(slab.tsdf_fuser_pred.tsdf.tsdf_values.shape) == (400, 400, 160)
+        sf = par.KeyframeShardFuser(dev, 1, 0, (H, W), fuser=slab, force_collective=True, mode="slab")
+        assert sf.slab == (0, 400)
+        sizes = [2, 2, 2]
+        starts = np.cumsum([0] + sizes)
+        n = par.run_sharded_pass(len(sizes), lambda i: sizes[i],
+                                 lambda i: (d[starts[i]:starts[i + 1]], k[starts[i]:starts[i + 1]], t[starts[i]:starts[i + 1]]), sf)
+        for i in range(len(sizes)):
+            sl = slice(starts[i], starts[i + 1])
+            serial.fuse_frames(d[sl], k[sl], t[sl], None)
+        torch.cuda.synchronize()
+        assert n == 6 and sf.slabs_current
+        a, b = serial.tsdf_fuser_pred.tsdf, slab.tsdf_fuser_pred.tsdf
+        assert (a.tsdf_weights > 0).sum().item() > 100000
+        assert torch.equal(a.tsdf_values.view(torch.int16), b.tsdf_values.view(torch.int16))
+        assert torch.equal(a.tsdf_weights.view(torch.int16), b.tsdf_weights.view(torch.int16))
+        assert torch.equal(a.voxel_bitmap, b.voxel_bitmap)
+    finally:
+        dist.destroy_process_group()
