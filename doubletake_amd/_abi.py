@@ -88,7 +88,7 @@ SIGNATURES = {
     "dt_instnorm_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "dt_raster_depth_f32": (_I, [_P, _P, _L, _P, _P, _I, _I, _P, _P, _P]),
     "dt_raster_soup_depth_f32": (_I, [_P, _L, C.POINTER(_F), _F, _P, _P, _I, _I, _P, _P, _P]),
-    "dt_hint_from_depth_f32": (_I, [_P, _P, C.POINTER(_F), _F, _I, _I, _I, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P]),
+    "dt_hint_from_depth_f32": (_I, [_P, _P, C.POINTER(_F), _F, _I, _I, _I, _P, _P, _F, _I, _I, _P, _P, _P, _P, _I, _P]),
     "dt_tsdf_frame_params_floats": (_I, []),
     "dt_tsdf_frame_setup_f16": (_I, [_P, _P, _I, _I, _F, _F, _P, _P]),
     "dt_tsdf_integrate_f16": (_I, [_P, _P, _P, C.POINTER(_F), _F, _I, _I, _I, _P, _I, _I, _P,

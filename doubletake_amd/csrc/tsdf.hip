@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void hint_from_depth_kernel(const float* __res
                                                              const float* __restrict__ invK, const float* __restrict__ pose,
                                                              float thr, int h, int w, float* __restrict__ hint,
                                                              float* __restrict__ mask_f, uint8_t* __restrict__ mask_b,
-                                                             float* __restrict__ weights) {
+                                                             float* __restrict__ weights, int fp16_math) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= h * w) return;
   const int y = i / w, x = i - y * w;
@@ -309,8 +309,11 @@ __global__ __launch_bounds__(256) void hint_from_depth_kernel(const float* __res
   const float wx = pose[0] * cx + pose[1] * cy + pose[2] * cz + pose[3];
   const float wy = pose[4] * cx + pose[5] * cy + pose[6] * cz + pose[7];
   const float wz = pose[8] * cx + pose[9] * cy + pose[10] * cz + pose[11];
-  const float sw = sample_trilinear(wvol, ox, oy, oz, vs, X, Y, Z, wx, wy, wz, 0);
-  const bool keep = (d != -1.0f) && !(sw < thr) && (d == d);
+  // fp16_math: grid and result rounded to half and the cut compared in half, as the reference's device branch would
+  // (tools/tsdf.py:327-330: a half volume on the GPU keeps grid_sample in half; `sampled < 0.025` on a half tensor)
+  const float sw = sample_trilinear(wvol, ox, oy, oz, vs, X, Y, Z, wx, wy, wz, fp16_math);
+  const float cut = (fp16_math && thr == thr && fabsf(thr) < 65504.f) ? rh(thr) : thr;
+  const bool keep = (d != -1.0f) && !(sw < cut) && (d == d);
   hint[i] = keep ? d : __builtin_nanf("");
   mask_f[i] = keep ? 1.0f : 0.0f;
   mask_b[i] = keep ? 1 : 0;
@@ -421,14 +424,14 @@ int dt_tsdf_sample_f16(const uint16_t* volume, const float* origin3, float voxel
 int dt_hint_from_depth_f32(const float* depth_hw, const uint16_t* weights_vol_f16, const float* origin3, float voxel_size,
                            int X, int Y, int Z, const float* invK_44, const float* world_T_cam_44, float threshold,
                            int h, int w, float* hint_hw, float* mask_hw, uint8_t* mask_b_hw, float* sampled_weights_hw,
-                           dt_stream_t s) {
+                           int fp16_math, dt_stream_t s) {
   DT_REQUIRE(depth_hw && weights_vol_f16 && origin3 && invK_44 && world_T_cam_44 && hint_hw && mask_hw &&
                  mask_b_hw && sampled_weights_hw,
              "dt_hint_from_depth_f32: null pointer");
   DT_REQUIRE(X > 1 && Y > 1 && Z > 1 && h > 0 && w > 0 && voxel_size > 0.f, "dt_hint_from_depth_f32: bad extents");
   DT_LAUNCH(hint_from_depth_kernel, dim3((unsigned)((h * w + 255) / 256)), dim3(256), 0, to_stream(s), depth_hw,
                      weights_vol_f16, origin3[0], origin3[1], origin3[2], voxel_size, X, Y, Z, invK_44, world_T_cam_44, threshold, h, w, hint_hw,
-                     mask_hw, mask_b_hw, sampled_weights_hw);
+                     mask_hw, mask_b_hw, sampled_weights_hw, fp16_math);
   return check_launch("dt_hint_from_depth_f32");
 }
 

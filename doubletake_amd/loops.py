@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _abi
+from .tools import tsdf as _tsdf_mod
 from .utils.rendering_utils import MeshDepthRenderer, empty_hint, prepare_mesh_hint, prepare_mesh_hint_fused
 
 
@@ -224,7 +225,8 @@ def hints_from_mesh(mesh, hint_fuser, renderer, cur_data, render_hw, hint_world_
     for j in range(b):  # the reference samples element by element too (:334-341)
         _abi.check(L.dt_hint_from_depth_f32(_abi.ptr(depth[j]), _abi.ptr(tsdf.tsdf_weights), o, float(tsdf.voxel_size), X, Y, Z,
                                             _abi.ptr(invK[j]), _abi.ptr(pose[j]), float("-inf"), H2, W2, _abi.ptr(hint[j]),
-                                            _abi.ptr(mask_f[j]), _abi.ptr(mask_b[j]), _abi.ptr(weights[j]), stream),
+                                            _abi.ptr(mask_f[j]), _abi.ptr(mask_b[j]), _abi.ptr(weights[j]),
+                                            int(_tsdf_mod.SAMPLE_FP16_MATH), stream),
                    "dt_hint_from_depth_f32")
     cur_data["depth_hint_b1hw"] = hint
     cur_data["depth_hint_mask_b_b1hw"] = mask_b

@@ -94,6 +94,15 @@ def _recover_origin_f32(voxel_coords_3hwd, voxel_size):
     return origin
 
 
+#: Arithmetic of the trilinear sampling of the half volume (TSDF.sample_tsdf and the fused hint kernel) when the caller
+#: does not say.  False: fp32 blend of the half voxels -- the reference's CPU branch (tools/tsdf.py:327-330), which is what
+#: the goldens pin.  True: grid and result rounded to half and the 0.025 cut compared in half, as the reference does when the
+#: volume lives on the GPU; that branch cannot be executed here (no CUDA device), so it stays an opt-in model of it.  What the
+#: choice changes on the incremental loop is measured by tests/test_incremental_cfg4_gpu.py (hint pixels within half
+#: precision of the cut) and stated in DESIGN.md section 2.  Environment override: DT_TSDF_SAMPLE_FP16=1.
+SAMPLE_FP16_MATH = os.environ.get("DT_TSDF_SAMPLE_FP16", "0") == "1"
+
+
 class TSDF:
     VOX_MOD = 8
 
@@ -221,9 +230,11 @@ class TSDF:
         )
 
     # -- sampling ---------------------------------------------------------------------------------------
-    def sample_tsdf(self, world_points_N3, what_to_sample="tsdf", sampling_method="bilinear", fp16_math=False):
+    def sample_tsdf(self, world_points_N3, what_to_sample="tsdf", sampling_method="bilinear", fp16_math=None):
         """tools/tsdf.py:277-339 (trilinear, align_corners=True).  fp32 math on the half volume (the
-        reference's pinned CPU branch) unless fp16_math=True."""
+        reference's pinned CPU branch) unless fp16_math=True (None: the module default SAMPLE_FP16_MATH)."""
+        if fp16_math is None:
+            fp16_math = SAMPLE_FP16_MATH
         if not (world_points_N3.ndim == 2 and world_points_N3.shape[1] == 3):
             raise ValueError("world_points_N3 must have shape (N, 3)! Instead got shape {}".format(world_points_N3.shape))
         if sampling_method not in ("bilinear", "trilinear"):

@@ -8,6 +8,7 @@ from __future__ import annotations
 import torch
 
 from .. import _abi
+from ..tools import tsdf as _tsdf_mod
 
 
 class MeshDepthRenderer:
@@ -82,7 +83,8 @@ def prepare_mesh_hint(fuser, mesh_renderer, cur_data, render_height, render_widt
 
 
 @torch.no_grad()
-def prepare_mesh_hint_fused(fuser, cur_data, render_height, render_width, weight_threshold=0.025, via_soup=False):
+def prepare_mesh_hint_fused(fuser, cur_data, render_height, render_width, weight_threshold=0.025, via_soup=False,
+                            fp16_math=None):
     """Same outputs as prepare_mesh_hint without an intermediate mesh object and without a host read: marching cubes
     fused with the depth render (dt_mc_raster_depth_f32: z-buffer init, one kernel that compacts each workgroup's
     triangles in LDS and rasterises them, resolve) -> back-projection + weight sampling + threshold.  The rendered image
@@ -126,7 +128,9 @@ def prepare_mesh_hint_fused(fuser, cur_data, render_height, render_width, weight
     X, Y, Z = tsdf.tsdf_weights.shape
     _abi.check(L.dt_hint_from_depth_f32(_abi.ptr(depth), _abi.ptr(tsdf.tsdf_weights), o, float(tsdf.voxel_size), X, Y, Z,
                                         _abi.ptr(invK), _abi.ptr(pose), float(weight_threshold), h, w, _abi.ptr(hint),
-                                        _abi.ptr(mask_f), _abi.ptr(mask_b), _abi.ptr(weights), stream), "dt_hint_from_depth_f32")
+                                        _abi.ptr(mask_f), _abi.ptr(mask_b), _abi.ptr(weights),
+                                        int(_tsdf_mod.SAMPLE_FP16_MATH if fp16_math is None else fp16_math), stream),
+               "dt_hint_from_depth_f32")
     cur_data["depth_hint_b1hw"] = hint
     cur_data["depth_hint_mask_b_b1hw"] = mask_b
     cur_data["depth_hint_mask_b1hw"] = mask_f

@@ -406,12 +406,14 @@ int dt_mc_raster_depth_f32(const uint16_t* values_f16, const uint32_t* active, i
 /* Hint maps from a rendered depth in one pass (test_incremental.py:204-258): back-project pixel centres
  * with invK / world_T_cam (device, 16 floats each, row-major 4x4), trilinearly sample the fused
  * weight volume, keep depth where rendered (!= -1) and weight >= threshold.  Outputs [h,w]:
- * hint (NaN where dropped), mask (1/0 float), mask_b (1/0 bytes), sampled weights (0 where dropped). */
+ * hint (NaN where dropped), mask (1/0 float), mask_b (1/0 bytes), sampled weights (0 where dropped).
+ * fp16_math: as in dt_tsdf_sample_f16 (0 = fp32 blend on the half volume, the pinned branch; 1 = grid, result and cut in
+ * half like the reference's device branch, unpinned). */
 int dt_hint_from_depth_f32(const float* depth_hw, const uint16_t* weights_vol_f16, const float* origin3,
                            float voxel_size, int X, int Y, int Z, const float* invK_44,
                            const float* world_T_cam_44, float threshold, int h, int w,
                            float* hint_hw, float* mask_hw, uint8_t* mask_b_hw,
-                           float* sampled_weights_hw, dt_stream_t s);
+                           float* sampled_weights_hw, int fp16_math, dt_stream_t s);
 
 /* ---- voxel-block (sparse) fp32 TSDF ------------------------------------------
  * replaces: CustomOpen3dFuser (tools/fusers_helper.py:263-511) over Open3D's VoxelBlockGrid (open3d==0.18.0,
