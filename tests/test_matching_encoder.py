@@ -283,3 +283,72 @@ def test_antialiased_maxpool_kernels_reproduce_hand_derived_cases(case):
     for ch, sc in enumerate(_SCALES):
         assert torch.equal(fused[0, ch], want * sc) and torch.equal(two[0, ch], want * sc), (case["name"], ch)
         assert torch.equal(alone[0, ch], torch.tensor(case["blur"], dtype=torch.float32) * sc)
+
+
+# ---- second, independent formulation of the anti-aliased max-pool -----------------------------------
+def _maxblur_separable_numpy(x):
+    """MaxPool2d(2, stride 1) + BlurPool(filt 4, stride 2) written WITHOUT convolutions or torch padding ops: explicit
+    reflected index arithmetic and two separable 1-D binomial passes [1, 3, 3, 1] / 8 (rows, then columns) in float64.
+    Reflection (no edge repeat) of index i on [0, n): -1 -> 1, n -> n - 2, n + 1 -> n - 3 (ReflectionPad2d((1, 2, 1, 2)))."""
+    x = np.asarray(x, dtype=np.float64)
+    m = np.maximum(np.maximum(x[..., :-1, :-1], x[..., :-1, 1:]), np.maximum(x[..., 1:, :-1], x[..., 1:, 1:]))
+    taps = np.array([1.0, 3.0, 3.0, 1.0]) / 8.0
+
+    def reflect(i, n):
+        return -i if i < 0 else (2 * (n - 1) - i if i >= n else i)
+
+    def pass_1d(a, axis):
+        n = a.shape[axis]
+        n_out = (n + 3 - 4) // 2 + 1
+        out = []
+        for o in range(n_out):
+            acc = 0.0
+            for t_i, wgt in enumerate(taps):
+                acc = acc + wgt * np.take(a, reflect(2 * o + t_i - 1, n), axis=axis)
+            out.append(acc)
+        return np.stack(out, axis=axis)
+
+    return pass_1d(pass_1d(m, -2), -1)
+
+
+def test_separable_formulation_agrees_with_the_restatement_and_the_hand_cases():
+    """Three independent statements of the package's published rules must agree: the exact hand cases, the torch
+    restatement the oracle uses (2-D depthwise correlation after ReflectionPad2d), and the separable index-arithmetic
+    form above -- on the hand cases exactly and on random maps (odd and even sizes, incl. the smallest legal one) to
+    float rounding."""
+    import torch.nn.functional as F
+
+    from doubletake_amd.modules import matching_encoder as me
+
+    for case in _blur_handcases():
+        x = np.asarray(case["x"], dtype=np.float64)
+        np.testing.assert_allclose(_maxblur_separable_numpy(x[None, None])[0, 0], np.asarray(case["maxblur"]), rtol=0, atol=1e-12)
+    rng = np.random.default_rng(5)
+    for (h, w) in ((5, 7), (8, 8), (9, 12), (16, 21), (4, 5)):
+        x = rng.standard_normal((2, 3, h, w)).astype(np.float32)
+        blur = me.BlurPool(3)
+        xt = torch.from_numpy(x)
+        want = F.conv2d(F.pad(F.max_pool2d(xt, 2, 1), (1, 2, 1, 2), mode="reflect"), blur.filt, stride=2, groups=3).numpy()
+        got = _maxblur_separable_numpy(x)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_maxblur_kernels_agree_with_the_separable_formulation_on_random_maps():
+    """The HIP kernels (fused dt_maxblur_f32; dt_maxpool_f32 + dt_blurpool4_s2_f32) against the separable float64
+    formulation on random maps, not only on the hand cases."""
+    import gpu_util as gu
+    from doubletake_amd.modules import matching_encoder as me
+
+    rng = np.random.default_rng(6)
+    for (n, c, h, w) in ((1, 64, 120, 160), (2, 8, 9, 12), (1, 4, 17, 5), (3, 16, 32, 33)):
+        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+        xd = torch.from_numpy(x).to(gu.dev()).contiguous(memory_format=torch.channels_last)
+        blur = me.BlurPool(c).to(gu.dev())
+        want = _maxblur_separable_numpy(x)
+        fused = me.maxblur(xd, blur).cpu().numpy()
+        two = me.blurpool(me.maxpool(xd, 2, 1, 0), blur).cpu().numpy()
+        assert fused.shape == want.shape
+        np.testing.assert_allclose(fused, want, rtol=0, atol=3e-6)
+        np.testing.assert_allclose(two, want, rtol=0, atol=3e-6)

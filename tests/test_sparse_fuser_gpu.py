@@ -179,3 +179,48 @@ def test_device_camera_entry_point_equals_host_camera_entry_point():
     assert torch.equal(a.volume.block_keys(), b.volume.block_keys())
     assert torch.equal(a.volume.tsdf[: na * 4096], b.volume.tsdf[: na * 4096])
     assert torch.equal(a.volume.weight[: na * 4096], b.volume.weight[: na * 4096])
+
+
+def test_sparse_blocks_cover_what_the_dense_fuser_activates():
+    """cross-check of the voxel-block fuser's activation (Open3D's share: restated, unpinned)
+    against the dense OurFuser on the same frame and the same 0.04 m grid (dense origin = a multiple of the voxel size, so
+    voxel positions coincide).  The two reference fusers differ by design -- OurFuser: half arithmetic, pixel centres at
+    +0.5, free space in front of the surface updated too; CustomOpen3dFuser: fp32, round-to-pixel, blocks only around the
+    surface -- so what must hold is: (a) every voxel of the dense fuser's ACTIVE set (its truncation band,
+    tools/tsdf.py:506-523) lies in an allocated block; (b) on those voxels both hold an observation and the truncated
+    signed distances agree to what half voxel positions (~1e-3 m) and the half-pixel sampling offset allow."""
+    import gpu_util as gu
+    from doubletake_amd.tools.fusers_helper import OurFuser
+
+    f, depth, K, T = _fuse(1)
+    dense = OurFuser(None, 0.04, 3.0, bounds=BD)
+    d, k, t = (torch.from_numpy(a).to(gu.dev()) for a in (depth[:1], K[:1], T[:1]))
+    dense.fuse_frames(d, k, t, None)
+    torch.cuda.synchronize()
+    td = dense.tsdf_fuser_pred.tsdf
+    keys = td.active_keys().cpu().numpy().astype(np.int64)          # [N,3] dense voxel indices of the truncation band
+    assert keys.shape[0] > 2000
+    org = np.round(np.array([BD["xmin"], BD["ymin"], BD["zmin"]]) / 0.04).astype(np.int64)
+    glob = keys + org                                                # global voxel index = world position / voxel size
+    blk = np.floor_divide(glob, 16)
+    loc = glob - blk * 16
+    g = f.volume
+    n = g.num_blocks()
+    slot_of = {tuple(int(v) for v in kk): s for s, kk in enumerate(g.block_keys().cpu().numpy())}
+    slots = np.array([slot_of.get(tuple(b), -1) for b in blk.tolist()])
+    # (a) activation covers the dense band (a ray sample within rounding of a block face may land on either side)
+    assert (slots >= 0).mean() > 0.999, (slots < 0).sum()
+    ok = slots >= 0
+    ts = g.tsdf[: n * 4096].view(n, 16, 16, 16).cpu().numpy()
+    ws = g.weight[: n * 4096].view(n, 16, 16, 16).cpu().numpy()
+    sv = ts[slots[ok], loc[ok, 0], loc[ok, 1], loc[ok, 2]]
+    sw = ws[slots[ok], loc[ok, 0], loc[ok, 1], loc[ok, 2]]
+    dv = td.tsdf_values.cpu().numpy().astype(np.float32)[keys[ok, 0], keys[ok, 1], keys[ok, 2]]
+    dw = td.tsdf_weights.cpu().numpy().astype(np.float32)[keys[ok, 0], keys[ok, 1], keys[ok, 2]]
+    # (b) both observed the voxel; one frame: the value is that frame's truncated distance, the weight its confidence
+    both = (sw > 0) & (dw > 0)
+    assert both.mean() > 0.97
+    dt_ = np.abs(sv[both] - dv[both])
+    # (measured: median 0.020 = 2.4 mm, 95 % 0.085 -- the half-pixel sampling offset on the slanted synthetic surface)
+    assert np.median(dt_) < 0.04 and np.quantile(dt_, 0.95) < 0.15, (np.median(dt_), np.quantile(dt_, 0.95))
+    assert np.abs(sw[both] - dw[both]).max() < 2e-3    # conf^2 * 2.5 / 100 of nearly the same sampled depth
