@@ -330,12 +330,20 @@ def tsdf_roofline(device):
         tsdf = f.tsdf_fuser_pred.tsdf
         ms = _event_ms(lambda: tsdf.sample_tsdf(pts, what_to_sample="weights"), device, 20, 5)
         out[f"sample_{tag}"] = entry(ms, pts.shape[0] * (12.0 + 16.0 + 4.0), points=int(pts.shape[0]), kernels="tsdf_sample")
-        # marching cubes (count -> scan -> generate; includes the host read of the two counts)
-        _, verts, faces = f.get_mesh_pytorch3d()
-        nv, nf = int(verts.shape[0]), int(faces.shape[0])
-        ms = _event_ms(lambda: f.get_mesh_pytorch3d(), device, 8, 2)
-        out[f"marching_cubes_{tag}"] = entry(ms, X * Y * Z * 2.125 + 12.0 * nv + 24.0 * nf, verts=nv, faces=nf,
+        # marching cubes: the native part (count -> scan -> 8-byte host read -> generate: a triangle soup with int64 edge
+        # ids), and the whole to_mesh_pytorch3d call on top of it (torch.unique over the edge ids + re-indexing = the
+        # reference's own post-processing, utils/pytorch3d_extras.py:90-96, plain PyTorch-ROCm ops here as there)
+        from doubletake_amd.utils.pytorch3d_extras import marching_cubes_raw
+
+        soup, tris, _ = marching_cubes_raw(tsdf.tsdf_values, tsdf.voxel_bitmap, 0.0)
+        ns, nt = int(soup.shape[0]), int(tris.shape[0])
+        ms = _event_ms(lambda: marching_cubes_raw(tsdf.tsdf_values, tsdf.voxel_bitmap, 0.0), device, 8, 2)
+        out[f"marching_cubes_{tag}"] = entry(ms, X * Y * Z * 2.125 + (12.0 + 8.0) * ns + 24.0 * nt, soup_verts=ns, faces=nt,
                                               kernels="mc_count + mc_scan + mc_generate (+ 8-byte host read)")
+        _, verts, faces = f.get_mesh_pytorch3d()
+        ms = _event_ms(lambda: f.get_mesh_pytorch3d(), device, 8, 2)
+        out[f"marching_cubes_{tag}"]["to_mesh_pytorch3d_ms"] = ms
+        out[f"marching_cubes_{tag}"]["merged_verts"] = int(verts.shape[0])
         del f, tsdf
         torch.cuda.empty_cache()
     return out

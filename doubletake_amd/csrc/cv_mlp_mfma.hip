@@ -630,13 +630,20 @@ static const int* mlp_tile_order(int h, int w, hipStream_t st) {
   std::sort(keyed.begin(), keyed.end());
   std::vector<int> order(num_tiles);
   for (int i = 0; i < num_tiles; ++i) order[i] = keyed[i].second;
+  // The allocation and the blocking copy are "unsafe" calls for a stream capture in global mode: one in progress on ANOTHER
+  // stream of the process (this stream was checked above) would be invalidated.  For the duration of the two calls this
+  // thread therefore runs in relaxed capture mode, which exempts exactly such calls.  The table is small
+  // (one int per 32-pixel tile) and lives for the process: one per (device, h, w) ever used.
   int* dptr = nullptr;
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
   if (hipMalloc(&dptr, num_tiles * sizeof(int)) != hipSuccess ||
       hipMemcpy(dptr, order.data(), num_tiles * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipGetLastError();
     if (dptr) (void)hipFree(dptr);
     dptr = nullptr;
   }
+  if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
   g_tile_orders[key] = dptr;  // (a failed allocation is remembered as "row-major")
   return dptr;
 }

@@ -93,18 +93,37 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& block_
 
 __global__ __launch_bounds__(256) void mc_count_kernel(const McArgs a, int* __restrict__ block_sums,
                                                       int* __restrict__ block_cells) {
-  __shared__ int lds[256];
+  __shared__ int wsum[4], wcells[4];
   const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // a workgroup covers eight words of the active bitmap; where all eight are zero (most of a room-sized volume) nothing
+  // can be emitted: one scalar-cache read per wave instead of 256 classifications and two block scans
+  const uint4* aw = reinterpret_cast<const uint4*>(a.active + (size_t)blockIdx.x * 8);
+  const uint4 w0 = aw[0], w1 = aw[1];
+  if ((w0.x | w0.y | w0.z | w0.w | w1.x | w1.y | w1.z | w1.w) == 0u) {
+    if (threadIdx.x == 0) {
+      block_sums[blockIdx.x] = 0;
+      block_cells[blockIdx.x] = 0;
+    }
+    return;
+  }
   int i, j, k, ci;
   float val[8];
   const int n = classify(a, id, i, j, k, ci, val);
-  int tot;
-  block_exclusive_scan(n, lds, tot);
-  int cells;
-  block_exclusive_scan(n > 0 ? 1 : 0, lds, cells);
+  // totals only: wave reduction + four partials through LDS (the per-thread offsets are recomputed by mc_generate)
+  int tot = n, cells = n > 0 ? 1 : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    tot += __shfl_xor(tot, m, 64);
+    cells += __shfl_xor(cells, m, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    wsum[threadIdx.x >> 6] = tot;
+    wcells[threadIdx.x >> 6] = cells;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    block_sums[blockIdx.x] = tot;
-    block_cells[blockIdx.x] = cells;
+    block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    block_cells[blockIdx.x] = wcells[0] + wcells[1] + wcells[2] + wcells[3];
   }
 }
 
@@ -179,9 +198,15 @@ __global__ __launch_bounds__(256) void mc_generate_kernel(const McArgs a, const 
                                                          int64_t* __restrict__ ids, int num_verts) {
   __shared__ int lds[256];
   const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  {  // (same early exit as mc_count_kernel: no active voxel in this workgroup's eight bitmap words)
+    const uint4* aw = reinterpret_cast<const uint4*>(a.active + (size_t)blockIdx.x * 8);
+    const uint4 w0 = aw[0], w1 = aw[1];
+    if ((w0.x | w0.y | w0.z | w0.w | w1.x | w1.y | w1.z | w1.w) == 0u) return;
+  }
   int i = 0, j = 0, k = 0, ci = 0;
   float val[8];
   const int n = classify(a, id, i, j, k, ci, val);
+  if (__syncthreads_or(n) == 0) return;   // active voxels, but no surface cell
   int tot;
   const int local = block_exclusive_scan(n, lds, tot);
   if (n == 0) return;
@@ -237,10 +262,15 @@ __global__ __launch_bounds__(256) void mc_raster_kernel(const McArgs a, const Mc
   __shared__ int cell_ci[256];
   __shared__ unsigned short tri_rec[256 * 5];  // (owner thread << 3) | triangle index within the cell
   const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  {  // no active voxel in this workgroup's eight bitmap words: leave before any classification or barrier
+    const uint4* aw = reinterpret_cast<const uint4*>(a.active + (size_t)blockIdx.x * 8);
+    const uint4 w0 = aw[0], w1 = aw[1];
+    if ((w0.x | w0.y | w0.z | w0.w | w1.x | w1.y | w1.z | w1.w) == 0u) return;
+  }
   int i = 0, j = 0, k = 0, ci = 0;
   float val[8];
   const int ntri = classify(a, id, i, j, k, ci, val) / 3;
-  if (__syncthreads_or(ntri) == 0) return;   // (most workgroups: no surface in their 256 cells)
+  if (__syncthreads_or(ntri) == 0) return;   // (active voxels, but no surface in their 256 cells)
   int tot;
   const int first = block_exclusive_scan(ntri, lds, tot);
   if (ntri > 0) {
