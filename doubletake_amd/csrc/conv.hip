@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct ConvArgs {
   const float* src[3];
+  unsigned src_bytes[3];  // extent of each source in bytes (raw-buffer range check of the Winograd patch loads)
   int c[3];
   int up[3];
   int nsrc;
@@ -660,6 +661,9 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) { c
 #ifndef DT_WABL
 #define DT_WABL 0
 #endif
+#ifndef DT_WINO_BUFLOAD
+#define DT_WINO_BUFLOAD 1  // 0 = the round-3 exec-masked global loads (A/B)
+#endif
 constexpr int kWinoTH = 4, kWinoTW = 8;                      // Winograd tiles per workgroup (rows, cols)
 constexpr int kWinoPH = 2 * kWinoTH + 2, kWinoPW = 2 * kWinoTW + 2;  // staged input patch 10 x 18
 // LDS layout of a staged 8-channel patch: [channel half][column parity][row (10)][column / 2, pitch 10][4 floats].
@@ -761,6 +765,43 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
   for (int b = 0; b < 4; ++b) w[b] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int it = 0; it < NLOAD; ++it) patch[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if DT_WINO_BUFLOAD
+  // Patch loads as RAW BUFFER loads (round 4): the hardware range check returns zeros for a byte offset beyond the source,
+  // so zero padding (offset -1 -> 0xFFFFFFFC) needs no compare / exec mask / zero-initialised destination, and the address is
+  // a 32-bit per-lane offset plus a scalar offset instead of 64-bit vector arithmetic.  On gfx950 every vector instruction
+  // in this loop costs fp32-MFMA time (scripts/mfma_filler_bench.hip): ~15 fewer per K step.
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src0), 0, a.src_bytes[0], 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src1 ? src1 : src0), 0, src1 ? a.src_bytes[1] : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src2 ? src2 : src0), 0, src2 ? a.src_bytes[2] : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_empty = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src0), 0, 0, 0x00020000);
+  // (byte offsets, once: -1 -> -4 = 0xFFFFFFFC stays out of range)
+#pragma unroll
+  for (int it = 0; it < NLOAD; ++it) {
+    poff0[it] *= 4;
+    poff1[it] *= 4;
+    poff2[it] *= 4;
+  }
+  // W = the weight register set to fill.  A group index past the layer's groups (the padding iterations of an uneven K
+  // split) loads zeros through the empty resource -- against the last group's weights, re-read harmlessly.
+#define DTW_PREFETCH_BUF(G, W)                                                                       \
+  do {                                                                                               \
+    const int gq_ = (G);                                                                             \
+    const bool live_ = gq_ < a.groups;                                                               \
+    const int g_ = live_ ? gq_ : a.groups - 1;                                                       \
+    const int sidx = (g_ < ng0) ? 0 : ((g_ < ng0 + ng1) ? 1 : 2);                                    \
+    const int gl = (sidx == 0) ? g_ : ((sidx == 1) ? g_ - ng0 : g_ - ng0 - ng1);                     \
+    const __amdgpu_buffer_rsrc_t rs = !live_ ? rs_empty : ((sidx == 0) ? rs0 : ((sidx == 1) ? rs1 : rs2)); \
+    _Pragma("unroll") for (int it = 0; it < NLOAD; ++it) {                                           \
+      const int off = (sidx == 0) ? poff0[it] : ((sidx == 1) ? poff1[it] : poff2[it]);               \
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));                                    \
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, gl * 32, 0);                  \
+      patch[it] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)); \
+    }                                                                                                \
+    const float4* wg = wbase + (size_t)g_ * (16 * 64);                                               \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                    \
+      W[b] = (DT_WABL & 1) ? make_float4((float)g_, (float)b, 1.f, 2.f) : wg[b * 64];                \
+  } while (0)
+#else
 #define DTW_PREFETCH(G)                                                                              \
   do {                                                                                               \
     const int g_ = (G);                                                                              \
@@ -777,6 +818,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
     _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                    \
       w[b] = (DT_WABL & 1) ? make_float4((float)g_, (float)b, 1.f, 2.f) : wg[b * 64];                \
   } while (0)
+#endif
 
   // every K-split group runs the same number of iterations so that the workgroup barriers line up; a group
   // whose share is exhausted stages zeros against (re-read, harmless) weights
@@ -795,6 +837,52 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
 #else
 #define DTW_STAMP(K) do { } while (0)
 #endif
+#if DT_WINO_BUFLOAD
+  // One K step against the weight set WC while the next step's patch and weights (into WN) are in flight.  The loop below is
+  // unrolled by two with the two weight sets swapping roles, so no register copy separates the steps.
+#define DTW_STEP(I, WC, WN)                                                                                           \
+  do {                                                                                                                \
+    const int g = g_base + ks + (I) * g_stride;                                                                       \
+    float* buf = lds + ((I) & 1) * kWinoPatchFloats;                                                                  \
+    _Pragma("unroll") for (int it = 0; it < NLOAD; ++it) {                                                            \
+      const int idx = (tid >> 1) + it * 128;                                                                          \
+      if (idx < NPIX) *reinterpret_cast<float4*>(buf + wino_lds_off(tid & 1, idx / kWinoPW, idx % kWinoPW)) = patch[it]; \
+    }                                                                                                                 \
+    DTW_STAMP(0);                                                                                                     \
+    if (!(DT_WABL & 8)) __syncthreads();                                                                              \
+    DTW_STAMP(1);                                                                                                     \
+    if ((I) + 1 < iters) DTW_PREFETCH_BUF(g + g_stride, WN);                                                          \
+    DTW_STAMP(2);                                                                                                     \
+    float4 tcol[4];                                                                                                   \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                   \
+      const float4 u = *reinterpret_cast<const float4*>(buf + wo1[c]);                                                \
+      const float4 v = *reinterpret_cast<const float4*>(buf + wo2[c]);                                                \
+      tcol[c] = make_float4(u.x + sgn * v.x, u.y + sgn * v.y, u.z + sgn * v.z, u.w + sgn * v.w);                      \
+    }                                                                                                                 \
+    float4 V[4];                                                                                                      \
+    V[0] = make_float4(tcol[0].x - tcol[2].x, tcol[0].y - tcol[2].y, tcol[0].z - tcol[2].z, tcol[0].w - tcol[2].w);   \
+    V[1] = make_float4(tcol[1].x + tcol[2].x, tcol[1].y + tcol[2].y, tcol[1].z + tcol[2].z, tcol[1].w + tcol[2].w);   \
+    V[2] = make_float4(tcol[2].x - tcol[1].x, tcol[2].y - tcol[1].y, tcol[2].z - tcol[1].z, tcol[2].w - tcol[1].w);   \
+    V[3] = make_float4(tcol[1].x - tcol[3].x, tcol[1].y - tcol[3].y, tcol[1].z - tcol[3].z, tcol[1].w - tcol[3].w);   \
+    DTW_STAMP(3);                                                                                                     \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                                   \
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(WC[b].x, V[b].x, acc[b], 0, 0, 0);                                \
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(WC[b].y, V[b].y, acc[b], 0, 0, 0);                                \
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(WC[b].z, V[b].z, acc[b], 0, 0, 0);                                \
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(WC[b].w, V[b].w, acc[b], 0, 0, 0);                                \
+    }                                                                                                                 \
+    DTW_STAMP(4);                                                                                                     \
+  } while (0)
+  float4 w2[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) w2[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (iters > 0) DTW_PREFETCH_BUF(g_base + ks, w);
+  for (int i = 0; i < iters; i += 2) {
+    DTW_STEP(i, w, w2);
+    if (i + 1 < iters) DTW_STEP(i + 1, w2, w);
+  }
+#undef DTW_STEP
+#else
   if (g_base + ks < a.groups) DTW_PREFETCH(g_base + ks);
   for (int i = 0; i < iters; ++i) {
     const int g = g_base + ks + i * g_stride;
@@ -846,6 +934,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
     }
     DTW_STAMP(4);  // issue of the 16 MFMAs (an MFMA issues when the pipe takes it)
   }
+#endif
 #ifdef DT_CONV_TIMING
   if (a.timing && (threadIdx.x & 63) == 0 && wave == DT_WINO_TIMING_WAVE && ks == 0) {
     unsigned long long* o = a.timing + (size_t)vblock * 8;
@@ -855,7 +944,11 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
   }
 #endif
 #undef DTW_STAMP
+#if DT_WINO_BUFLOAD
+#undef DTW_PREFETCH_BUF
+#else
 #undef DTW_PREFETCH
+#endif
 
   // ---- inverse transform: columns in registers, rows across the four waves through LDS ----------------
   __syncthreads();  // all waves are done with the patch buffers
@@ -940,7 +1033,9 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
 }
 
 template <int KSPLIT>
-__global__ __launch_bounds__(256 * KSPLIT, conv_waves_per_eu(256 * KSPLIT)) void conv_wino_kernel(const ConvArgs a) {
+// (KSPLIT = 1: three 256-thread workgroups per CU -- the register budget the chip-filling layers are tuned for -- is requested
+// explicitly: left alone, the compiler spends registers on the unrolled K loop and drops to two)
+__global__ __launch_bounds__(256 * KSPLIT, (KSPLIT == 1 ? 3 : conv_waves_per_eu(256 * KSPLIT))) void conv_wino_kernel(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_all[8192 * KSPLIT];
   conv_wino_body<KSPLIT>(a, lds_all, blockIdx.x, gridDim.x);
 }
@@ -952,7 +1047,7 @@ __global__ __launch_bounds__(256 * KSPLIT, conv_waves_per_eu(256 * KSPLIT)) void
 // blocks [0, nblocks_a) run convolution A, the rest convolution B, each with its own ConvArgs and virtual block index.
 // Both bodies must use the same workgroup size.
 template <class BodyA, class BodyB>
-__global__ __launch_bounds__(BodyA::THREADS, conv_waves_per_eu(BodyA::THREADS)) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, unsigned nblocks_a) {
+__global__ __launch_bounds__(BodyA::THREADS, (BodyA::THREADS == 256 ? 3 : conv_waves_per_eu(BodyA::THREADS))) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, unsigned nblocks_a) {
   static_assert(BodyA::THREADS == BodyB::THREADS, "paired convolutions need equal workgroup sizes");
   constexpr int LDSF = BodyA::LDS_FLOATS > BodyB::LDS_FLOATS ? BodyA::LDS_FLOATS : BodyB::LDS_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDSF > 0 ? LDSF : 4];
@@ -1148,6 +1243,7 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
   a.groups = 0;
   for (int s = 0; s < 3; ++s) {
     a.src[s] = nullptr;
+    a.src_bytes[s] = 0;
     a.c[s] = 0;
     a.up[s] = 0;
   }
@@ -1160,6 +1256,11 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
     a.c[s] = d->c[s];
     a.up[s] = d->up[s] ? 1 : 0;
     a.groups += d->c[s] >> 3;
+    {  // bytes of the source as stored (a nearest-upsampled source is read at half resolution)
+      const size_t px = (size_t)d->n * (d->up[s] ? d->h_in / 2 : d->h_in) * (d->up[s] ? d->w_in / 2 : d->w_in);
+      const size_t bytes = px * (size_t)d->c[s] * sizeof(float);
+      a.src_bytes[s] = bytes < 0xFFFFF000ull ? (unsigned)bytes : 0xFFFFF000u;  // (larger sources: range check effectively off)
+    }
   }
   DT_REQUIRE(out != nullptr, "%s: null output", who);
   a.nsrc = d->nsrc;
