@@ -8,6 +8,6 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for c in "$@"; do
   timeout -s KILL 90 rocprofv3 --kernel-trace --pmc "$c" --output-format csv -d "$R/gpurun_out/${TAG}_$c" -o pmc -- \
-    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --streams 1 > "$R/gpurun_out/${TAG}_$c.err" 2>&1
+    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-side-legs --streams 1 > "$R/gpurun_out/${TAG}_$c.err" 2>&1
   echo "$c rc=$?"
 done

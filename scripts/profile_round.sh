@@ -9,12 +9,15 @@ OUT="$R/gpurun_out/$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 [ -n "$SKIP_TRACE" ] || timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d "$OUT/trace" -o bench -- \
-  python "$R/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --streams 1 > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
+  python "$R/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --no-side-legs --streams 1 > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 echo "trace rc=$?"
-for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
+# (round 4: instruction-mix and wait counters for the per-kernel account of where SIMD time goes; a counter this gfx950
+#  build does not know fails its own pass only)
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE" \
+         "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_SMEM"; do
   n=$(echo $c | tr ' ' '_')
   timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$n" -o pmc -- \
-    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --streams 1 > "$OUT/pmc_$n.err" 2>&1
+    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-side-legs --streams 1 > "$OUT/pmc_$n.err" 2>&1
   echo "pmc $c rc=$?"
 done
 cd "$R"
