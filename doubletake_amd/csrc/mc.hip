@@ -17,8 +17,8 @@
 // one host read of two ints instead of four .item() syncs + two device synchronisations.
 //
 // Two phases over the same thread->voxel mapping (256 consecutive voxel ids per block):
-//   count:    per-block vertex totals -> single-block exclusive scan -> total in counts_out
-//   generate: recompute the per-thread count, block-local scan in LDS, write vertices / faces / ids
+//   count:    per-block vertex totals -> two-level exclusive scan (chunks of 4096 blocks) -> totals in counts_out
+//   generate: reclassify, block-local scan of triangle counts in LDS, one thread per triangle writes vertices / faces / ids
 #include "common.hpp"
 #include "mc_tables.hpp"
 #include "raster_device.hpp"
@@ -127,19 +127,70 @@ __global__ __launch_bounds__(256) void mc_count_kernel(const McArgs a, int* __re
   }
 }
 
-// exclusive scan of block_sums in place (single block, 1024 threads, chunked) + totals.
-// Per-thread chunk sums are scanned with wave shuffles, the 16 wave totals through LDS.
-__global__ __launch_bounds__(1024) void mc_scan_kernel(int* __restrict__ block_sums, const int* __restrict__ block_cells,
-                                                      int nblocks, int* __restrict__ counts_out) {
+// Exclusive scan of block_sums in two launches (round 4: the single-workgroup version walked 98 strided elements per thread
+// -- 258 us at 0.02 m, more than count and generate together).
+//   mc_scan1: one 1024-thread workgroup per chunk of 4096 block sums: coalesced int4 load, exclusive scan inside the chunk
+//             (written back in place), chunk total of vertices and of cells
+//   mc_scan2: one workgroup scans the chunk totals (exclusive, in place) and writes the grand totals to counts_out
+// mc_generate adds the chunk prefix to the in-chunk offset.
+constexpr int kScanChunk = 4096;
+
+__global__ __launch_bounds__(1024) void mc_scan1_kernel(int* __restrict__ block_sums, const int* __restrict__ block_cells,
+                                                       int nblocks, long long* __restrict__ chunk_tot,
+                                                       long long* __restrict__ chunk_cells) {
+  __shared__ int wtot[16];
+  __shared__ int ctot[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int e0 = blockIdx.x * kScanChunk + t * 4;
+  int v[4], c = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] = (e0 + q < nblocks) ? block_sums[e0 + q] : 0;
+    c += (e0 + q < nblocks) ? block_cells[e0 + q] : 0;
+  }
+  const int mine = v[0] + v[1] + v[2] + v[3];
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+  if (lane == 63) wtot[wave] = incl;
+  if (lane == 0) ctot[wave] = c;
+  __syncthreads();
+  int base = 0, total = 0, cells = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int x = wtot[w];
+    if (w < wave) base += x;
+    total += x;
+    cells += ctot[w];
+  }
+  int run = base + incl - mine;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (e0 + q < nblocks) block_sums[e0 + q] = run;
+    run += v[q];
+  }
+  if (t == 0) {
+    chunk_tot[blockIdx.x] = total;    // (a chunk holds at most 4096 x 256 x 15 vertices: fits an int; the prefix may not)
+    chunk_cells[blockIdx.x] = cells;
+  }
+}
+
+__global__ __launch_bounds__(1024) void mc_scan2_kernel(long long* __restrict__ chunk_tot, const long long* __restrict__ chunk_cells,
+                                                       int nchunks, int* __restrict__ counts_out) {
   __shared__ long long wtot[16];
   __shared__ long long ctot[16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int per = (nblocks + 1023) / 1024;
-  const int b0 = min(t * per, nblocks), b1 = min(b0 + per, nblocks);
+  const int per = (nchunks + 1023) / 1024;
+  const int b0 = min(t * per, nchunks), b1 = min(b0 + per, nchunks);
   long long s = 0, c = 0;
   for (int b = b0; b < b1; ++b) {
-    s += block_sums[b];
-    c += block_cells[b];
+    s += chunk_tot[b];
+    c += chunk_cells[b];
   }
   long long incl = s;
 #pragma unroll
@@ -166,8 +217,8 @@ __global__ __launch_bounds__(1024) void mc_scan_kernel(int* __restrict__ block_s
   }
   long long run = base + incl - s;
   for (int b = b0; b < b1; ++b) {
-    const int v = block_sums[b];
-    block_sums[b] = (int)run;
+    const long long v = chunk_tot[b];
+    chunk_tot[b] = run;
     run += v;
   }
 }
@@ -193,10 +244,17 @@ __device__ __forceinline__ void vertex_interp(float iso, float p1x, float p1y, f
   oz = p1z * (1 - ratio) + p2z * ratio;
 }
 
+// One thread per TRIANGLE (round 4; was one thread per cell writing up to 15 vertices with 12-byte strided stores): the
+// workgroup classifies its 256 cells, compacts (cell, triangle) records through LDS -- the scheme of mc_raster_kernel below -- and
+// thread q then builds triangle q of the workgroup: 36 contiguous bytes of vertices, 24 of edge ids, 24 of face indices, so a wave
+// writes whole cache lines.  Output order unchanged: ascending voxel id, the case table's triangle order within a cell.
 __global__ __launch_bounds__(256) void mc_generate_kernel(const McArgs a, const int* __restrict__ block_offsets,
-                                                         float* __restrict__ verts, int64_t* __restrict__ faces,
+                                                         const long long* __restrict__ chunk_prefix, float* __restrict__ verts, int64_t* __restrict__ faces,
                                                          int64_t* __restrict__ ids, int num_verts) {
   __shared__ int lds[256];
+  __shared__ float cell_val[256][9];           // 8 corner values (+1 pad)
+  __shared__ int cell_ci[256];
+  __shared__ unsigned short tri_rec[256 * 5];  // (owner thread << 3) | triangle index within the cell
   const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
   {  // (same early exit as mc_count_kernel: no active voxel in this workgroup's eight bitmap words)
     const uint4* aw = reinterpret_cast<const uint4*>(a.active + (size_t)blockIdx.x * 8);
@@ -205,35 +263,48 @@ __global__ __launch_bounds__(256) void mc_generate_kernel(const McArgs a, const 
   }
   int i = 0, j = 0, k = 0, ci = 0;
   float val[8];
-  const int n = classify(a, id, i, j, k, ci, val);
-  if (__syncthreads_or(n) == 0) return;   // active voxels, but no surface cell
+  const int ntri = classify(a, id, i, j, k, ci, val) / 3;
+  if (__syncthreads_or(ntri) == 0) return;   // active voxels, but no surface cell
   int tot;
-  const int local = block_exclusive_scan(n, lds, tot);
-  if (n == 0) return;
-  const int base = block_offsets[blockIdx.x] + local;
+  const int first = block_exclusive_scan(ntri, lds, tot);
+  if (ntri > 0) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cell_val[threadIdx.x][c] = val[c];
+    cell_ci[threadIdx.x] = ci;
+    for (int t = 0; t < ntri; ++t) tri_rec[first + t] = (unsigned short)((threadIdx.x << 3) | t);
+  }
+  __syncthreads();
+  const size_t base_id = (size_t)blockIdx.x * 256;
+  const long long tri_base = ((long long)block_offsets[blockIdx.x] + chunk_prefix[blockIdx.x / kScanChunk]) / 3;
   // MC naming: x = k (Z axis, fastest), y = j, z = i;  W = Z, H = Y, D = X
   const long long W = a.Z, H = a.Y, D = a.X;
   const long long hash_mul = W + W * H + W * H * D;
-  for (int t = 0; t < n; ++t) {
-    const int e = kMcEdges[ci][t];
-    const int c1 = kEdgeCodes[e][0], c2 = kEdgeCodes[e][1];
-    const int x1 = k + (c1 & 1), y1 = j + ((c1 >> 1) & 1), z1 = i + ((c1 >> 2) & 1);
-    const int x2 = k + (c2 & 1), y2 = j + ((c2 >> 1) & 1), z2 = i + ((c2 >> 2) & 1);
-    float ox, oy, oz;
-    vertex_interp(a.iso, (float)x1, (float)y1, (float)z1, (float)x2, (float)y2, (float)z2, val[c1], val[c2], ox, oy, oz);
-    const int idx = base + t;
-    if (idx < num_verts) {
-      verts[(size_t)idx * 3 + 0] = ox;
-      verts[(size_t)idx * 3 + 1] = oy;
-      verts[(size_t)idx * 3 + 2] = oz;
+  for (int q = threadIdx.x; q < tot; q += 256) {
+    const int rec = tri_rec[q];
+    const int owner = rec >> 3, t3 = (rec & 7) * 3;
+    const size_t oid = base_id + owner;
+    const int ok = (int)(oid % a.Z), oj = (int)((oid / a.Z) % a.Y), oi = (int)(oid / ((size_t)a.Z * a.Y));
+    const int oci = cell_ci[owner];
+    const long long tri = tri_base + q;
+    if (tri * 3 + 2 >= num_verts) continue;
+    float* vo = verts + tri * 9;
+    int64_t* io = ids + tri * 3;
+    int64_t* fo = faces + tri * 3;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int e = kMcEdges[oci][t3 + v];
+      const int c1 = kEdgeCodes[e][0], c2 = kEdgeCodes[e][1];
+      const int x1 = ok + (c1 & 1), y1 = oj + ((c1 >> 1) & 1), z1 = oi + ((c1 >> 2) & 1);
+      const int x2 = ok + (c2 & 1), y2 = oj + ((c2 >> 1) & 1), z2 = oi + ((c2 >> 2) & 1);
+      float ox, oy, oz;
+      vertex_interp(a.iso, (float)x1, (float)y1, (float)z1, (float)x2, (float)y2, (float)z2, cell_val[owner][c1],
+                    cell_val[owner][c2], ox, oy, oz);
+      vo[v * 3 + 0] = ox;
+      vo[v * 3 + 1] = oy;
+      vo[v * 3 + 2] = oz;
       const long long v1 = x1 + y1 * W + z1 * W * H, v2 = x2 + y2 * W + z2 * W * H;
-      ids[idx] = v1 * hash_mul + v2;
-      if (t % 3 == 0) {
-        const size_t f = (size_t)idx / 3;
-        faces[f * 3 + 0] = idx;
-        faces[f * 3 + 1] = idx + 1;
-        faces[f * 3 + 2] = idx + 2;
-      }
+      io[v] = v1 * hash_mul + v2;
+      fo[v] = tri * 3 + v;
     }
   }
 }
@@ -331,7 +402,9 @@ extern "C" {
 
 int64_t dt_mc_workspace_bytes(int X, int Y, int Z) {
   const size_t nblocks = ((size_t)X * Y * Z + 255) / 256;
-  return (int64_t)(2 * nblocks * sizeof(int));
+  const size_t nchunks = (nblocks + kScanChunk - 1) / kScanChunk;
+  // [block sums | block cells] ints (padded to 8 bytes), then [chunk totals | chunk cells] 64-bit
+  return (int64_t)(((2 * nblocks + 1) / 2 * 2) * sizeof(int) + 2 * nchunks * sizeof(long long));
 }
 
 int dt_mc_count(const uint16_t* values, const uint32_t* active, int X, int Y, int Z, float isolevel, const int* mn,
@@ -343,8 +416,12 @@ int dt_mc_count(const uint16_t* values, const uint32_t* active, int X, int Y, in
   DT_REQUIRE(nblocks < 2147483647ull, "dt_mc_count: volume too large");
   int* sums = reinterpret_cast<int*>(workspace);
   int* cells = sums + nblocks;
+  const size_t nchunks = (nblocks + kScanChunk - 1) / kScanChunk;
+  long long* ctot = reinterpret_cast<long long*>(sums + (2 * nblocks + 1) / 2 * 2);
+  long long* ccells = ctot + nchunks;
   DT_LAUNCH(mc_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, to_stream(s), a, sums, cells);
-  DT_LAUNCH(mc_scan_kernel, dim3(1), dim3(1024), 0, to_stream(s), sums, cells, (int)nblocks, counts_out);
+  DT_LAUNCH(mc_scan1_kernel, dim3((unsigned)nchunks), dim3(1024), 0, to_stream(s), sums, cells, (int)nblocks, ctot, ccells);
+  DT_LAUNCH(mc_scan2_kernel, dim3(1), dim3(1024), 0, to_stream(s), ctot, ccells, (int)nchunks, counts_out);
   return check_launch("dt_mc_count");
 }
 
@@ -358,8 +435,12 @@ int dt_mc_generate(const uint16_t* values, const uint32_t* active, int X, int Y,
   if (num_verts == 0) return 0;
   DT_REQUIRE(verts && faces && ids, "dt_mc_generate: null output");
   const size_t nblocks = (size_t)X * Y * Z / 256;
-  DT_LAUNCH(mc_generate_kernel, dim3((unsigned)nblocks), dim3(256), 0, to_stream(s), a,
-                     reinterpret_cast<const int*>(workspace), verts, faces, ids, num_verts);
+  const size_t nchunks = (nblocks + kScanChunk - 1) / kScanChunk;
+  const int* sums = reinterpret_cast<const int*>(workspace);
+  const long long* cprefix = reinterpret_cast<const long long*>(sums + (2 * nblocks + 1) / 2 * 2);
+  (void)nchunks;
+  DT_LAUNCH(mc_generate_kernel, dim3((unsigned)nblocks), dim3(256), 0, to_stream(s), a, sums, cprefix, verts, faces, ids,
+                     num_verts);
   return check_launch("dt_mc_generate");
 }
 
