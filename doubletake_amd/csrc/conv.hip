@@ -661,6 +661,9 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) { c
 #ifndef DT_WABL
 #define DT_WABL 0
 #endif
+#ifndef DT_WINO1_WPE
+#define DT_WINO1_WPE 3  // waves per SIMD requested for the 256-thread Winograd / pair kernels (4 = 128 registers: spills, A/B)
+#endif
 #ifndef DT_WINO_BUFLOAD
 #define DT_WINO_BUFLOAD 1  // 0 = the round-3 exec-masked global loads (A/B)
 #endif
@@ -752,12 +755,12 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
   const int r2 = (wave == 0) ? 2 : ((wave == 1) ? 2 : ((wave == 2) ? 1 : 3));
   const float sgn = (wave == 1) ? 1.0f : -1.0f;
   // LDS offsets of the eight window positions this lane reads per group: rows r1 / r2, columns 0..3
-  int wo1[4], wo2[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    wo1[c] = wino_lds_off(half, 2 * ty + r1, 2 * tx + c);
-    wo2[c] = wino_lds_off(half, 2 * ty + r2, 2 * tx + c);
-  }
+  // (column c of the window = column 2*tx + c of the patch: parity c & 1, slot tx + (c >> 1), i.e. a CONSTANT distance from
+  //  column 0 -- the four reads of a row share one address register and differ in the instruction's immediate offset)
+  const int wo1_0 = wino_lds_off(half, 2 * ty + r1, 2 * tx), wo2_0 = wino_lds_off(half, 2 * ty + r2, 2 * tx);
+  constexpr int kWoff[4] = {0, kWinoPH * kWinoRowPitch * 4, 4, kWinoPH * kWinoRowPitch * 4 + 4};
+#define wo1(c) (wo1_0 + kWoff[c])
+#define wo2(c) (wo2_0 + kWoff[c])
 
   float4 patch[NLOAD];
   float4 w[4];
@@ -855,8 +858,8 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
     DTW_STAMP(2);                                                                                                     \
     float4 tcol[4];                                                                                                   \
     _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                   \
-      const float4 u = *reinterpret_cast<const float4*>(buf + wo1[c]);                                                \
-      const float4 v = *reinterpret_cast<const float4*>(buf + wo2[c]);                                                \
+      const float4 u = *reinterpret_cast<const float4*>(buf + wo1(c));                                                \
+      const float4 v = *reinterpret_cast<const float4*>(buf + wo2(c));                                                \
       tcol[c] = make_float4(u.x + sgn * v.x, u.y + sgn * v.y, u.z + sgn * v.z, u.w + sgn * v.w);                      \
     }                                                                                                                 \
     float4 V[4];                                                                                                      \
@@ -911,9 +914,9 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float4 u = (DT_WABL & 4) ? make_float4(acc[0][c], 1.f, 2.f, (float)g)
-                                     : *reinterpret_cast<const float4*>(buf + wo1[c]);
+                                     : *reinterpret_cast<const float4*>(buf + wo1(c));
       const float4 v = (DT_WABL & 4) ? make_float4(acc[1][c], 3.f, 1.f, (float)c)
-                                     : *reinterpret_cast<const float4*>(buf + wo2[c]);
+                                     : *reinterpret_cast<const float4*>(buf + wo2(c));
       tcol[c] = make_float4(u.x + sgn * v.x, u.y + sgn * v.y, u.z + sgn * v.z, u.w + sgn * v.w);
     }
     float4 V[4];
@@ -943,6 +946,8 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
     o[6] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
+#undef wo1
+#undef wo2
 #undef DTW_STAMP
 #if DT_WINO_BUFLOAD
 #undef DTW_PREFETCH_BUF
@@ -1035,7 +1040,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* __restr
 template <int KSPLIT>
 // (KSPLIT = 1: three 256-thread workgroups per CU -- the register budget the chip-filling layers are tuned for -- is requested
 // explicitly: left alone, the compiler spends registers on the unrolled K loop and drops to two)
-__global__ __launch_bounds__(256 * KSPLIT, (KSPLIT == 1 ? 3 : conv_waves_per_eu(256 * KSPLIT))) void conv_wino_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256 * KSPLIT, (KSPLIT == 1 ? DT_WINO1_WPE : conv_waves_per_eu(256 * KSPLIT))) void conv_wino_kernel(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_all[8192 * KSPLIT];
   conv_wino_body<KSPLIT>(a, lds_all, blockIdx.x, gridDim.x);
 }
@@ -1047,7 +1052,7 @@ __global__ __launch_bounds__(256 * KSPLIT, (KSPLIT == 1 ? 3 : conv_waves_per_eu(
 // blocks [0, nblocks_a) run convolution A, the rest convolution B, each with its own ConvArgs and virtual block index.
 // Both bodies must use the same workgroup size.
 template <class BodyA, class BodyB>
-__global__ __launch_bounds__(BodyA::THREADS, (BodyA::THREADS == 256 ? 3 : conv_waves_per_eu(BodyA::THREADS))) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, unsigned nblocks_a) {
+__global__ __launch_bounds__(BodyA::THREADS, (BodyA::THREADS == 256 ? DT_WINO1_WPE : conv_waves_per_eu(BodyA::THREADS))) void conv_pair_kernel(const ConvArgs a, const ConvArgs b, unsigned nblocks_a) {
   static_assert(BodyA::THREADS == BodyB::THREADS, "paired convolutions need equal workgroup sizes");
   constexpr int LDSF = BodyA::LDS_FLOATS > BodyB::LDS_FLOATS ? BodyA::LDS_FLOATS : BodyB::LDS_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDSF > 0 ? LDSF : 4];
