@@ -45,6 +45,11 @@
 
 namespace dt {
 
+#ifdef DT_DOT_TIMING
+// experiment builds only (scripts/dot_wave_times.py): per-wave (start, end) realtime stamps (100 MHz) of the last launch
+__device__ unsigned long long g_dot_times[16384 * 3];
+#endif
+
 constexpr int kDotTile = 8;            // a wave owns an 8 x 8 pixel tile, one pixel per lane
 #ifndef DT_DOT_CAP
 #define DT_DOT_CAP 208
@@ -95,6 +100,9 @@ __global__ __launch_bounds__(64 * kDotWaves, DT_DOT_OCC) void cv_dot_lds_kernel(
   constexpr int C = 16;
   __shared__ __attribute__((aligned(16))) float box_all[kDotWaves * kDotCapTexels * C];
 
+#ifdef DT_DOT_TIMING
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* box = box_all + wave * (kDotCapTexels * C);
@@ -354,6 +362,16 @@ __global__ __launch_bounds__(64 * kDotWaves, DT_DOT_OCC) void cv_dot_lds_kernel(
     }
     d0 = d1;
   }
+#ifdef DT_DOT_TIMING
+  if (lane == 0) {
+    const unsigned slot = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * kDotWaves + wave;
+    if (slot < 16384) {
+      g_dot_times[slot * 3 + 0] = t_begin;
+      g_dot_times[slot * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+      g_dot_times[slot * 3 + 2] = ((unsigned long long)blockIdx.y << 32) | (unsigned)(blockIdx.x * kDotWaves + wave);
+    }
+  }
+#endif
 }
 
 }  // namespace dt
@@ -361,6 +379,12 @@ __global__ __launch_bounds__(64 * kDotWaves, DT_DOT_OCC) void cv_dot_lds_kernel(
 using namespace dt;
 
 extern "C" {
+
+#ifdef DT_DOT_TIMING
+int dt_debug_dot_times(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dot_times), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#endif
 
 static int dot_launch(int mode, const float* cur, const float* src, const float* params, float* vol, int batch, int num_src,
                       int channels, int h, int w, int num_planes, int* stats, dt_stream_t s, const char* what) {
@@ -375,6 +399,12 @@ static int dot_launch(int mode, const float* cur, const float* src, const float*
   // planes per wave: up to 8, fewer while the grid has fewer than ~4 workgroups per CU -- the units differ a lot in cost
   // (near planes split into many small boxes), so a B=1 frame needs the finer grain to balance: measured at cfg2
   // 8 planes 0.105 ms, 4 planes 0.087 ms, 2 planes 0.091 ms; at B=8 (3072 workgroups with 8 planes) 8 planes stay best
+  // Round 4 (scripts/dot_wave_times.py -> profiles/r4u_dot_wave_times.txt): at cfg2 every wave is busy for 21-44 us whatever
+  // its planes (vector-instruction throughput: 121 plain + 40 packed per wave-sample), so the launch lasts two rounds of the 768
+  // resident workgroup slots, the second 56 % full.  Tried against that: one balanced span of 6-7 planes per wave, all resident
+  // at once (0.109 ms against 0.089: ranges of more than 4 planes stage worse, as with the fixed 8-plane grid); half-size groups
+  // at the far end of the plane list cannot shorten the schedule either (1.56 rounds of work need quarter-size units to beat 2.0,
+  // and single-plane ranges are not worth staging).
   int group = kDotMaxGroup;
   while (group > 2 && (long)wgs * batch * ((num_planes + group - 1) / group) < 1024) group >>= 1;
   static const int force_group = [] { const char* e = getenv("DT_DOT_GROUP"); return e ? atoi(e) : 0; }();  // tuning hook
