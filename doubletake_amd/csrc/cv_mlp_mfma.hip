@@ -52,6 +52,13 @@ __host__ __device__ inline int mlp_w1dyn_floats(int K) { return K * kStepsPerVie
 __host__ __device__ inline int mlp_w1pix_floats(int K) { return (kPixFixed + 2 * K) * kStepFloats; }
 constexpr int kW2Floats = kW2Steps * kStepFloats;
 
+#ifdef DT_MLP_TIMING
+// experiment builds only (scripts/mlp_wave_times.py): per-wave (start, end, first-task end, id) realtime stamps of the last
+// launch (100 MHz counter) and the time at the end of each of a wave's first 24 planes
+__device__ unsigned long long g_mlp_times[4096 * 4];
+__device__ unsigned long long g_mlp_prog[2048 * 24];
+#endif
+
 struct MlpArgs {
   const float* cur;       // [b,16,h,w]
   const float* src;       // [b,K,h,w,16]
@@ -70,7 +77,8 @@ struct MlpArgs {
   int B, K, h, w, D;
   int num_tiles;          // 32-pixel tiles per batch element
   const int* tile_order;  // [num_tiles] position in the processing order -> tile, or null (row-major order)
-  long total_units;       // B * num_tiles * D (tile, plane) units, split evenly over the resident waves
+  long total_units;       // B * num_tiles * D (tile, plane) units, split over the resident waves
+  int old_share_q16;      // share (x 65536) of a workgroup's units that its older four waves take (32768 = even split)
 };
 
 // LeakyReLU(0.01) in two vector instructions: max(x, 0.01 x) == med3(x, 0.01 x, +inf) exactly; fmaxf() costs a third one
@@ -275,14 +283,34 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
   // the per-view parameter reads below are scalar loads (SGPR operands, scalar cache).
   int remaining, d0, otile, b;  // otile: position in the tile order
   {
-    const long u = wid * a.total_units / waves_total;
-    const long u_end = (wid + 1) * a.total_units / waves_total;
+    // Weighted split inside a workgroup (round 4).  With two waves per SIMD the older wave of a pair (waves 0-3) wins the issue
+    // arbitration and runs ~32 us per plane against ~43 for its partner (scripts/mlp_wave_times.py): with equal spans it
+    // finished ~130 us early and the partner ran the rest alone, at a lower pipe rate.  The workgroup's contiguous share of the
+    // span space is therefore cut in a.old_share : (1 - a.old_share) between the older and the younger half of its waves, so
+    // that partners finish together.  NWAVES = 4 (one wave per SIMD) keeps the even split.
+    long u, u_end;
+    if (NWAVES == 8 && a.old_share_q16 != 32768) {
+      const long g0 = (long)lbid * a.total_units / nblk, g1 = ((long)lbid + 1) * a.total_units / nblk;  // this workgroup's units
+      const long cut = g0 + (g1 - g0) * a.old_share_q16 / 65536;                                        // older half | younger half
+      const long lo = (wave < 4) ? g0 : cut, hi = (wave < 4) ? cut : g1;
+      const int wq = wave & 3;
+      u = lo + (hi - lo) * wq / 4;
+      u_end = lo + (hi - lo) * (wq + 1) / 4;
+    } else {
+      u = wid * a.total_units / waves_total;
+      u_end = (wid + 1) * a.total_units / waves_total;
+    }
     const long tile_global = u / D;
     d0 = __builtin_amdgcn_readfirstlane((int)(u - tile_global * D));
     otile = __builtin_amdgcn_readfirstlane((int)(tile_global % a.num_tiles));
     b = __builtin_amdgcn_readfirstlane((int)(tile_global / a.num_tiles));
     remaining = __builtin_amdgcn_readfirstlane((int)(u_end - u));
   }
+#ifdef DT_MLP_TIMING
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t_first = 0;
+  int planes_done = 0;
+#endif
   for (; remaining > 0;) {
     const int d1 = min(D, d0 + remaining);
     const int tile = a.tile_order ? ((const int __attribute__((address_space(4)))*)(uintptr_t)a.tile_order)[otile] : otile;  // (wave-uniform: one scalar load per task)
@@ -571,7 +599,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
           __builtin_amdgcn_wave_barrier();
         }
       }
+#ifdef DT_MLP_TIMING
+      if (lane == 0 && wid < 2048 && planes_done < 24) g_mlp_prog[wid * 24 + planes_done] = __builtin_amdgcn_s_memrealtime();
+      ++planes_done;
+#endif
     }
+#ifdef DT_MLP_TIMING
+    if (t_first == 0) t_first = __builtin_amdgcn_s_memrealtime();
+#endif
     // next task of the span: the following planes of the same tile, else plane 0 of the next tile / batch element
     remaining -= d1 - d0;
     d0 = d1;
@@ -583,6 +618,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
       }
     }
   }
+#ifdef DT_MLP_TIMING
+  if (lane == 0 && wid < 4096) {
+    g_mlp_times[wid * 4 + 0] = t_begin;
+    g_mlp_times[wid * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    g_mlp_times[wid * 4 + 2] = t_first;
+    g_mlp_times[wid * 4 + 3] = ((unsigned long long)blockIdx.x << 8) | (unsigned)wave;
+  }
+#endif
 }
 
 
@@ -658,6 +701,16 @@ using namespace dt;
 
 extern "C" {
 
+#ifdef DT_MLP_TIMING
+// experiment builds only (not in the header): copy the stamps of the last launch to the host
+int dt_debug_mlp_times(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_times), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+int dt_debug_mlp_progress(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_prog), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int dt_cv_mlp_pack_floats(int num_src, int* w1dyn, int* w1pix, int* w2p, int* tail) {
   DT_REQUIRE(num_src > 0 && num_src <= kMaxSrcStream, "dt_cv_mlp_pack_floats: num_src=%d not in 1..%d", num_src, kMaxSrcStream);
   if (w1dyn) *w1dyn = mlp_w1dyn_floats(num_src);
@@ -687,6 +740,8 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
   a.tile_order = mlp_tile_order(h, w, to_stream(s));
   const int cus = num_cus();
   a.total_units = (long)batch * a.num_tiles * num_planes;
+  static const int old_share = [] { const char* e = getenv("DT_MLP_OLD_SHARE"); const double v = e ? atof(e) : 0.61; return (int)(65536.0 * (v > 0.2 && v < 0.9 ? v : 0.5)); }();
+  a.old_share_q16 = old_share;
   const int nw = (num_src > kMaxSrcMfma) ? 4 : g_mlp_waves;  // streamed views: one wave per SIMD (register room for the loads in flight)
   const bool stream = num_src > kMaxSrcMfma;  // more views than LDS holds: the further views' fragments come from L2
   const size_t lds_bytes = (size_t)(mlp_w1dyn_floats(stream ? kMaxSrcMfma : num_src) + kW2Floats + kTailFloats + kHintFloats +

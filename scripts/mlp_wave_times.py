@@ -48,6 +48,14 @@ def main():
     # waves of one SIMD pair (wave w and w+4 of a block share a SIMD): how far apart do partners finish?
     e = end.reshape(-1, 8)
     out["partner_end_gap_us_pct"] = np.percentile(np.abs(e[:, :4] - e[:, 4:]), [50, 90, 100]).round(2).tolist()
+    # if the two waves of every SIMD shared their work dynamically, a SIMD would finish at about the mean of its pair; if a CU's
+    # eight waves did, at the CU mean: how far apart are THOSE?  (what a pair- / CU-level split can and cannot recover)
+    pair_mean = (e[:, :4] + e[:, 4:]) / 2.0
+    cu_mean = e.mean(axis=1)
+    out["simd_pair_mean_end_us_pct"] = np.percentile(pair_mean, [0, 10, 50, 90, 100]).round(1).tolist()
+    out["cu_mean_end_us_pct"] = np.percentile(cu_mean, [0, 10, 50, 90, 100]).round(1).tolist()
+    out["kernel_if_pairs_balanced_us"] = float(pair_mean.max())
+    out["kernel_if_all_balanced_us"] = float(end.mean())
     print(json.dumps(out, indent=1))
     # progress curves: time per plane of the two waves of a SIMD while both run, and of the survivor alone
     pb = (ctypes.c_ulonglong * (n * 24))()
