@@ -78,6 +78,7 @@ struct MlpArgs {
   int num_tiles;          // 32-pixel tiles per batch element
   const int* tile_order;  // [num_tiles] position in the processing order -> tile, or null (row-major order)
   long total_units;       // B * num_tiles * D (tile, plane) units, split over the resident waves
+  const int* span_bounds; // [gridDim.x * NWAVES + 1] first unit of every wave's span from the cost-aware plan, or null (even / weighted split)
   int old_share_q16;      // share (x 65536) of a workgroup's units that its older four waves take (32768 = even split)
 };
 
@@ -289,7 +290,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
     // span space is therefore cut in a.old_share : (1 - a.old_share) between the older and the younger half of its waves, so
     // that partners finish together.  NWAVES = 4 (one wave per SIMD) keeps the even split.
     long u, u_end;
-    if (NWAVES == 8 && a.old_share_q16 != 32768) {
+    if (a.span_bounds) {  // cost-aware plan (mlp_plan_* below): spans of equal estimated work
+      const int* sb = a.span_bounds + (long)lbid * NWAVES + wave;
+      u = sb[0];
+      u_end = sb[1];
+    } else if (NWAVES == 8 && a.old_share_q16 != 32768) {
       const long g0 = (long)lbid * a.total_units / nblk, g1 = ((long)lbid + 1) * a.total_units / nblk;  // this workgroup's units
       const long cut = g0 + (g1 - g0) * a.old_share_q16 / 65536;                                        // older half | younger half
       const long lo = (wave < 4) ? g0 : cut, hi = (wave < 4) ? cut : g1;
@@ -629,6 +634,142 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
 }
 
 
+// ---- cost-aware span plan (round 4) -------------------------------------------------------------------------------------
+// The hint kernel skips the 32 feature MFMAs of every (32-pixel tile, plane, view) whose footprint misses the source image.  On
+// the bench frame that is 8.7 % of all MFMAs -- but with spans of equal LENGTH the saving is spread unevenly: near planes and
+// border tiles are cheap, and per-wave stamps (scripts/mlp_wave_times.py) showed waves finishing anywhere between 560 and 830 us
+// with the launch waiting for the last.  Two small kernels in front of the volume kernel give every wave a span of equal
+// estimated WORK instead:
+//   mlp_plan_cost:   one thread per (batch, tile, plane) unit: projects the tile's first, middle and last pixel into every view
+//                    (same arithmetic as the volume kernel) and prices the unit as kPlanFixed + 27 K + 32 x (views seen)
+//                    (MFMAs of layer 2 + metadata steps + the unit's vector work in MFMA equivalents; 32 per visible view)
+//   mlp_plan_bounds: one workgroup: prefix sum of the prices, then the unit at which every wave's share begins -- a workgroup gets
+//                    1 / gridDim of the total, its older four waves old_share of that (see the kernel), in equal parts
+// The plan only moves span boundaries: every (pixel, plane) value is computed by the same code whichever wave owns it.
+constexpr int kPlanFixed = 290;
+__host__ __device__ inline int mlp_plan_bound_ints(int cus) { return (cus * 8 + 1 + 1) / 2 * 2; }  // (+1 end marker, even count)
+__host__ __device__ inline long mlp_plan_groups(long units) { return (units + 255) / 256; }         // workgroups of the pricing kernel
+
+// prices of 256 consecutive units -> their inclusive prefix inside the group (pref) + the group total (gsum)
+__global__ __launch_bounds__(256) void mlp_plan_cost_kernel(const float* __restrict__ params, const int* __restrict__ tile_order,
+                                                           unsigned* __restrict__ pref, unsigned* __restrict__ gsum, int B, int K,
+                                                           int h, int w, int D, int num_tiles, long total_units) {
+  __shared__ unsigned wsum[4];
+  const long u = (long)blockIdx.x * 256 + threadIdx.x;
+  unsigned c = 0;
+  if (u < total_units) {
+    const long tg = u / D;
+    const int d = (int)(u - tg * D), otile = (int)(tg % num_tiles), b = (int)(tg / num_tiles);
+    const int tile = tile_order ? tile_order[otile] : otile;
+    const float* p = params + (size_t)b * cv_params_floats(D, K);
+    const int hw = h * w;
+    const float depth = p[kCvPlanes + d];
+    const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
+    int seen = 0;  // bit k: view k touches the image from at least one of the three sample pixels
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) {
+      const int pix = min(tile * 32 + sp * 16 - (sp == 2 ? 1 : 0), hw - 1);  // pixels 0, 16, 31 of the tile
+      const int y = pix / w, x = pix - y * w;
+      float rx, ry, rz;
+      pixel_ray(p + kCvInvK, x, y, rx, ry, rz);
+      for (int k = 0; k < K; ++k) {
+        const ViewProj q = project_view(p + cv_view_off(D, k), depth * rx, depth * ry, depth * rz);
+        const float gx = 2.0f * q.u * inv_w - 1.0f, gy = 2.0f * q.v * inv_h - 1.0f;
+        const float ix = ((gx + 1.0f) * (float)w - 1.0f) * 0.5f, iy = ((gy + 1.0f) * (float)h - 1.0f) * 0.5f;
+        if ((ix > -1.0f) & (ix < (float)w) & (iy > -1.0f) & (iy < (float)h)) seen |= 1 << k;
+      }
+    }
+    c = (unsigned)(kPlanFixed + 27 * K + 32 * __builtin_popcount(seen));
+  }
+  unsigned incl = c;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned base = 0;
+  for (int q = 0; q < wave; ++q) base += wsum[q];
+  if (u < total_units) pref[u] = base + incl;
+  if (threadIdx.x == 255) gsum[blockIdx.x] = base + incl;
+}
+
+// one thread per wave slot j (+ the end marker): bounds[j] = first unit of slot j's span = the number of units whose cumulative
+// price stays below the slot's target
+__global__ __launch_bounds__(256) void mlp_plan_bounds_kernel(const unsigned* __restrict__ pref, const unsigned* __restrict__ gsum,
+                                                             long total_units, int ngroups, int nblk, int nwaves,
+                                                             int old_share_q16, int* __restrict__ bounds) {
+  extern __shared__ long gpre[];  // [ngroups + 1] exclusive prefix of the group totals
+  __shared__ long wtot[4];
+  // exclusive scan of gsum by the whole workgroup (every workgroup of this kernel repeats it: ngroups is a few hundred)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int per = (ngroups + 255) / 256;
+  const int g0 = min(t * per, ngroups), g1 = min(g0 + per, ngroups);
+  long s = 0;
+  for (int g = g0; g < g1; ++g) s += gsum[g];
+  long incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const long up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  long base = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < wave) base += wtot[q];
+    total += wtot[q];
+  }
+  long run = base + incl - s;
+  for (int g = g0; g < g1; ++g) {
+    gpre[g] = run;
+    run += gsum[g];
+  }
+  if (t == 0) gpre[ngroups] = total;
+  __syncthreads();
+  const long nslots = (long)nblk * nwaves;
+  const long j = (long)blockIdx.x * 256 + t;
+  if (j > nslots) return;
+  // cumulative price at which slot j begins: workgroup blk gets 1 / nblk of the total (remainder spread over the first ones),
+  // inside it the older four waves old_share of that in equal parts, the younger four the rest
+  long target;
+  if (j == nslots) {
+    target = total;
+  } else {
+    const long blk = j / nwaves;
+    const int wv = (int)(j - blk * nwaves);
+    const long share = total / nblk, rem = total - share * nblk;
+    const long b0 = blk * share + min(blk, rem), b1 = b0 + share + (blk < rem ? 1 : 0);
+    if (nwaves == 8) {
+      const long cut = b0 + (((b1 - b0) * old_share_q16) >> 16);
+      target = (wv < 4) ? b0 + (((cut - b0) * wv) >> 2) : cut + (((b1 - cut) * (wv - 4)) >> 2);
+    } else {
+      target = b0 + (b1 - b0) * wv / nwaves;
+    }
+  }
+  int out = 0;
+  if (target > 0) {
+    // group whose cumulative range (gpre[g], gpre[g + 1]] holds the target, then the unit inside it
+    int lo = 0, hi = ngroups - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (gpre[mid + 1] >= target) hi = mid; else lo = mid + 1;
+    }
+    const long in_group = target - gpre[lo];  // 1 .. group total
+    const long ubase = (long)lo * 256;
+    int a = 0, c = (int)min(255L, total_units - 1 - ubase);
+    while (a < c) {
+      const int mid = (a + c) >> 1;
+      if ((long)pref[ubase + mid] >= in_group) c = mid; else a = mid + 1;
+    }
+    out = (int)(ubase + a + 1);  // the span begins behind the unit that reaches the target
+  }
+  bounds[j] = out;
+}
+
 // Tile processing order.  A wave's span and an XCD's eighth of the span space are contiguous in this order, and every XCD
 // fetches the source texels its eighth's epipolar segments touch into its own L2.  Row-major order makes an eighth a band of
 // h/8 rows over the full width, whose footprint under a horizontal baseline is fine but under any vertical parallax covers
@@ -720,11 +861,11 @@ int dt_cv_mlp_pack_floats(int num_src, int* w1dyn, int* w1pix, int* w2p, int* ta
   return 0;
 }
 
-int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, const float* w1dyn,
-                       const float* w1pix, const float* w2p, const float* tail, const float* hint_mlp,
-                       const float* depth_hint, const float* hint_weights, const float* hint_mask, int hint_h,
-                       int hint_w, float* volume, int out_nhwc, int batch, int num_src, int h, int w,
-                       int num_planes, dt_stream_t s) {
+static int mlp_hint_launch(const float* cur, const float* src, const float* params, const float* w1dyn,
+                           const float* w1pix, const float* w2p, const float* tail, const float* hint_mlp,
+                           const float* depth_hint, const float* hint_weights, const float* hint_mask, int hint_h,
+                           int hint_w, float* volume, int out_nhwc, int batch, int num_src, int h, int w,
+                           int num_planes, void* plan_scratch, dt_stream_t s) {
   DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0, "dt_cv_mlp_hint_f32: bad extents");
   DT_REQUIRE(num_src > 0 && num_src <= kMaxSrcStream, "dt_cv_mlp_hint_f32: num_src=%d not in 1..%d", num_src, kMaxSrcStream);
   DT_REQUIRE(cur && src && params && w1dyn && w1pix && w2p && tail && volume, "dt_cv_mlp_hint_f32: null pointer");
@@ -742,12 +883,27 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
   a.total_units = (long)batch * a.num_tiles * num_planes;
   static const int old_share = [] { const char* e = getenv("DT_MLP_OLD_SHARE"); const double v = e ? atof(e) : 0.61; return (int)(65536.0 * (v > 0.2 && v < 0.9 ? v : 0.5)); }();
   a.old_share_q16 = old_share;
+  a.span_bounds = nullptr;
   const int nw = (num_src > kMaxSrcMfma) ? 4 : g_mlp_waves;  // streamed views: one wave per SIMD (register room for the loads in flight)
   const bool stream = num_src > kMaxSrcMfma;  // more views than LDS holds: the further views' fragments come from L2
   const size_t lds_bytes = (size_t)(mlp_w1dyn_floats(stream ? kMaxSrcMfma : num_src) + kW2Floats + kTailFloats + kHintFloats +
                                     nw * kStageFloats) * sizeof(float);
   const long want = (a.total_units + nw - 1) / nw;  // at least one unit per wave
   const int blocks = (int)(want < cus ? want : cus);
+  // cost-aware span plan: only where units differ in cost (the hint kernel's empty-view skip) and for the tuned instantiation
+  static const bool plan_on = [] { const char* e = getenv("DT_MLP_PLAN"); return !(e && e[0] == '0'); }();
+  if (plan_scratch && plan_on && hint_mlp && !stream && nw == 8 && DT_MLP_SKIP_EMPTY && a.total_units < 2147483647L && mlp_plan_groups(a.total_units) < 8000) {
+    int* bounds = reinterpret_cast<int*>(plan_scratch);
+    const int ngroups = (int)mlp_plan_groups(a.total_units);
+    unsigned* gsum = reinterpret_cast<unsigned*>(bounds + mlp_plan_bound_ints(cus));
+    unsigned* pref = gsum + (ngroups + 1) / 2 * 2;
+    DT_LAUNCH(mlp_plan_cost_kernel, dim3((unsigned)ngroups), dim3(256), 0, to_stream(s), params, a.tile_order, pref, gsum, batch,
+              num_src, h, w, num_planes, a.num_tiles, a.total_units);
+    const int nslots = blocks * nw;
+    DT_LAUNCH(mlp_plan_bounds_kernel, dim3((unsigned)((nslots + 1 + 255) / 256)), dim3(256), (size_t)(ngroups + 1) * sizeof(long),
+              to_stream(s), pref, gsum, a.total_units, ngroups, blocks, nw, a.old_share_q16, bounds);
+    a.span_bounds = bounds;
+  }
 #define DT_LAUNCH_MLP(HINT_, NW_, ST_)                                                                             \
   do {                                                                                                             \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cv_mlp_mfma_kernel<HINT_, NW_, ST_>),          \
@@ -767,6 +923,33 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
   }
 #undef DT_LAUNCH_MLP
   return check_launch("dt_cv_mlp_hint_f32");
+}
+
+int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, const float* w1dyn,
+                       const float* w1pix, const float* w2p, const float* tail, const float* hint_mlp,
+                       const float* depth_hint, const float* hint_weights, const float* hint_mask, int hint_h,
+                       int hint_w, float* volume, int out_nhwc, int batch, int num_src, int h, int w,
+                       int num_planes, dt_stream_t s) {
+  return mlp_hint_launch(cur, src, params, w1dyn, w1pix, w2p, tail, hint_mlp, depth_hint, hint_weights, hint_mask, hint_h,
+                         hint_w, volume, out_nhwc, batch, num_src, h, w, num_planes, nullptr, s);
+}
+
+int64_t dt_cv_mlp_plan_bytes(int batch, int h, int w, int num_planes) {
+  if (batch <= 0 || h <= 0 || w <= 0 || num_planes <= 0) return 0;
+  const int64_t units = (int64_t)batch * (((int64_t)h * w + 31) / 32) * num_planes;
+  const int64_t ngroups = mlp_plan_groups(units);
+  // [span bounds int32][group totals uint32][in-group prefixes uint32 per unit]
+  return ((int64_t)mlp_plan_bound_ints(device_cu_count()) + (ngroups + 1) / 2 * 2 + units) * 4;
+}
+
+int dt_cv_mlp_hint_planned_f32(const float* cur, const float* src, const float* params, const float* w1dyn,
+                               const float* w1pix, const float* w2p, const float* tail, const float* hint_mlp,
+                               const float* depth_hint, const float* hint_weights, const float* hint_mask, int hint_h,
+                               int hint_w, float* volume, int out_nhwc, int batch, int num_src, int h, int w,
+                               int num_planes, void* plan_scratch, dt_stream_t s) {
+  DT_REQUIRE(plan_scratch != nullptr, "dt_cv_mlp_hint_planned_f32: null plan scratch (dt_cv_mlp_plan_bytes)");
+  return mlp_hint_launch(cur, src, params, w1dyn, w1pix, w2p, tail, hint_mlp, depth_hint, hint_weights, hint_mask, hint_h,
+                         hint_w, volume, out_nhwc, batch, num_src, h, w, num_planes, plan_scratch, s);
 }
 
 }  // extern "C"

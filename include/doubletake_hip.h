@@ -115,6 +115,19 @@ int dt_cv_mlp_hint_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc
                        const float* hint_mask_b1HW, int hint_h, int hint_w, float* volume,
                        int out_nhwc, int batch, int num_src, int h, int w, int num_planes,
                        dt_stream_t s);
+/* The same call with a COST-AWARE SPAN PLAN in front of the volume kernel (round 4): two small kernels price every (tile, plane)
+ * unit by the number of source views it can see (the hint kernel skips the feature contractions of views a tile does not see) and
+ * give every wave a span of equal estimated work instead of equal length.  Same volume bit for bit (the plan only moves span
+ * boundaries).  plan_scratch: device buffer of dt_cv_mlp_plan_bytes(batch, h, w, num_planes) bytes, owned by the caller, scratch
+ * for the duration of the call on stream s. */
+int64_t dt_cv_mlp_plan_bytes(int batch, int h, int w, int num_planes);
+int dt_cv_mlp_hint_planned_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc,
+                               const float* params, const float* w1dyn, const float* w1pix,
+                               const float* w2p, const float* tail, const float* hint_mlp,
+                               const float* depth_hint_b1HW, const float* hint_weights_b1HW,
+                               const float* hint_mask_b1HW, int hint_h, int hint_w, float* volume,
+                               int out_nhwc, int batch, int num_src, int h, int w, int num_planes,
+                               void* plan_scratch, dt_stream_t s);
 /* OPT-IN split-precision variant of dt_cv_mlp_hint_f32 (same reference functions, same arguments except the weights):
  * the two dense contractions run on v_mfma_f32_32x32x16_f16 with every operand split into fp16 hi + lo parts
  * (x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo, fp32 accumulation): fp32-class accuracy (dropped term 2^-22 relative) at 3/16

@@ -419,3 +419,44 @@ def test_uniform_plane_override_still_takes_the_tuned_kernel():
     torch.cuda.synchronize()
     assert m._planes_px is None and vol.is_contiguous(memory_format=torch.channels_last)
     assert np.abs(vol.cpu().numpy() - g["hint_volume"]).max() < 5e-5
+
+
+def test_cost_aware_span_plan_only_moves_boundaries():
+    """Round 4: dt_cv_mlp_hint_planned_f32 prices every (tile, plane) unit by the source views it can see and gives every wave
+    a span of equal estimated work.  The plan must cover the unit space exactly once (bounds start at 0, end at the unit count,
+    never decrease), price units between the all-empty and the all-visible cost, and leave the volume what the un-planned
+    call computes (to the ulp level of a differently contracted multiply-add) -- at cfg2 size, at batch 2 with a view behind the camera, and on a ragged image."""
+    import gpu_util as gu
+    from doubletake_amd.modules.cost_volume import FeatureMeshHintVolumeManager
+
+    for (b, k, h, w, D, seed) in ((1, 7, 120, 160, 64, 1), (2, 3, 48, 64, 32, 7), (1, 2, 19, 27, 16, 5)):
+        t = gu.to_dev(syn.volume_inputs(b, k, h, w, 16, seed))
+        m = FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+        gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 3)
+        gu.load_formula_mlp(m.hint_mlp, [3, 12, 12, 1], 4)
+        args, hd = gu.volume_call_args(t), gu.hint_dict(t)
+        m.use_span_plan = False
+        ref = m(**args, cv_depth_hint_dict=hd)[0].clone()
+        m.use_span_plan = True
+        got = m(**args, cv_depth_hint_dict=hd)[0]
+        torch.cuda.synchronize()
+        # (not bitwise: the first plane of a span goes through a separately inlined copy of the view set-up whose multiply-adds
+        #  the compiler may contract differently -- 1-2 ulp; every unit must have been computed, by exactly this arithmetic)
+        assert float((got - ref).abs().max()) < 2e-6, (b, k, h, w, D)
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        units = b * ((h * w + 31) // 32) * D
+        blocks = min(cus, (units + 7) // 8)
+        n_ints = (cus * 8 + 2) // 2 * 2
+        plan = m._last_plan.cpu().numpy()
+        bounds = plan[: 4 * n_ints].view(np.int32)[: blocks * 8 + 1]
+        ngroups = (units + 255) // 256
+        pref = plan[4 * (n_ints + (ngroups + 1) // 2 * 2):][: 4 * units].view(np.uint32).astype(np.int64)
+        cost = pref - np.where(np.arange(units) % 256 == 0, 0, np.roll(pref, 1))
+        assert bounds[0] == 0 and bounds[-1] == units and np.all(np.diff(bounds) >= 0), (bounds[:4], bounds[-4:], units)
+        assert cost.min() >= 290 + 27 * k and cost.max() <= 290 + 27 * k + 32 * k
+        if h * w >= 19200:  # the bench frame: spans really differ in length, their estimated work does not
+            work = np.add.reduceat(cost.astype(np.int64), bounds[:-1].clip(max=units - 1))
+            work[np.diff(bounds) == 0] = 0
+            older, younger = work.reshape(blocks, 8)[:, :4], work.reshape(blocks, 8)[:, 4:]
+            assert older.std() / older.mean() < 0.06 and younger.std() / younger.mean() < 0.08
+            assert np.diff(bounds).max() > np.diff(bounds).min() + 2
