@@ -148,7 +148,10 @@ __global__ __launch_bounds__(64 * kDotWaves, DT_DOT_OCC) void cv_dot_lds_kernel(
     pixel_ray(p + kCvInvK, cx, cy, crx, cry, crz);
   }
 
-  const int ds = blockIdx.y * group, de = min(ds + group, D);
+  // (round 4: handing the plane groups out far planes first -- the expensive ones, so that the partial second round of
+  //  workgroups would be the cheap near groups -- measured slower, 0.0845 -> 0.0885 ms at cfg2, 0.303 -> 0.314 at B=8)
+  const int pg = (int)blockIdx.y;
+  const int ds = pg * group, de = min(ds + group, D);
   int d0 = ds;
   while (d0 < de) {
     int d1 = de;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(64 * kDotWaves, DT_DOT_OCC) void cv_dot_lds_kernel(
     if (slot < 16384) {
       g_dot_times[slot * 3 + 0] = t_begin;
       g_dot_times[slot * 3 + 1] = __builtin_amdgcn_s_memrealtime();
-      g_dot_times[slot * 3 + 2] = ((unsigned long long)blockIdx.y << 32) | (unsigned)(blockIdx.x * kDotWaves + wave);
+      g_dot_times[slot * 3 + 2] = ((unsigned long long)pg << 32) | (unsigned)(blockIdx.x * kDotWaves + wave);
     }
   }
 #endif

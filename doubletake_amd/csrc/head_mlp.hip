@@ -37,8 +37,16 @@ __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : __expf(v) 
     ACC[3] = __builtin_amdgcn_mfma_f32_32x32x2f32((A4).w, (BVAL), ACC[3], 0, 0, 0); \
   } while (0)
 
+// Waves per workgroup of the persistent kernel (one workgroup per CU: the weights take 99-132 KB of LDS).  Two waves per SIMD:
+// while one waits for its next tile's inputs, its LDS operands or runs the ELUs, the other keeps the matrix pipe busy
+// (round 4, 240x320 head of cfg2: 51.4 us with four waves -> 44.2 with eight; same tiles, bit-identical output).
+#ifndef DT_HEAD_WAVES
+#define DT_HEAD_WAVES 8
+#endif
+constexpr int kHeadThreads = 64 * DT_HEAD_WAVES;
+
 template <int NG>  // NG = cin / 8 input groups (8 or 16)
-__global__ __launch_bounds__(256, 1) void head_mlp_kernel(const HeadArgs a) {
+__global__ __launch_bounds__(kHeadThreads, 1) void head_mlp_kernel(const HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_wa = lds;
   float* lds_wb = lds + NG * 4 * kHeadStep;
@@ -46,11 +54,11 @@ __global__ __launch_bounds__(256, 1) void head_mlp_kernel(const HeadArgs a) {
   {
     const float4* g1 = reinterpret_cast<const float4*>(a.wa);
     float4* l1 = reinterpret_cast<float4*>(lds_wa);
-    for (int i = threadIdx.x; i < NG * 4 * kHeadStep / 4; i += 256) l1[i] = g1[i];
+    for (int i = threadIdx.x; i < NG * 4 * kHeadStep / 4; i += kHeadThreads) l1[i] = g1[i];
     const float4* g2 = reinterpret_cast<const float4*>(a.wb);
     float4* l2 = reinterpret_cast<float4*>(lds_wb);
-    for (int i = threadIdx.x; i < 64 * kHeadStep / 4; i += 256) l2[i] = g2[i];
-    for (int i = threadIdx.x; i < kHeadTail; i += 256) lds_tail[i] = a.tail[i];
+    for (int i = threadIdx.x; i < 64 * kHeadStep / 4; i += kHeadThreads) l2[i] = g2[i];
+    for (int i = threadIdx.x; i < kHeadTail; i += kHeadThreads) lds_tail[i] = a.tail[i];
   }
   __syncthreads();
 
@@ -59,8 +67,8 @@ __global__ __launch_bounds__(256, 1) void head_mlp_kernel(const HeadArgs a) {
   const int half = lane >> 5, p = lane & 31;
   const int lane_off = (half * 32 + p) * 4;
   const long tiles = (a.pixels + 31) / 32;
-  const long waves_total = (long)gridDim.x * 4;
-  const long wid = (long)blockIdx.x * 4 + wave;
+  const long waves_total = (long)gridDim.x * DT_HEAD_WAVES;
+  const long wid = (long)blockIdx.x * DT_HEAD_WAVES + wave;
   long t = wid * tiles / waves_total;
   const long t_end = (wid + 1) * tiles / waves_total;  // balanced contiguous span of pixel tiles
   const float bc = lds_tail[384];
@@ -161,6 +169,8 @@ __device__ __forceinline__ void head_split_body(const HeadArgs& a, const unsigne
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = a.tail[half * 64 + wave * 16 + r];
   {
+    // (round 4: issuing all 96-192 A-operand loads of a wave up front -- 108-128 registers instead of 40 -- measured slower,
+    //  36 -> 39 us for the three coarse heads; the launch is bound by its dependent MFMA chains, not by these loads)
     const float* wl = a.wa + lane_off;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -269,7 +279,7 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
     return check_launch("dt_head_mlp_f32");
   }
   DT_REQUIRE(cin != 256, "dt_head_mlp_f32: cin=256 is only supported up to %ld pixel tiles (got %ld)", split_max_tiles, tiles);
-  const long want = (tiles + 3) / 4;
+  const long want = (tiles + DT_HEAD_WAVES - 1) / DT_HEAD_WAVES;
   const int blocks = (int)(want < g_head_cus ? want : g_head_cus);
   const size_t lds_bytes = (size_t)((cin / 2) * kHeadStep + 64 * kHeadStep + kHeadTail) * sizeof(float);
 #define DT_LAUNCH_HEAD(NG_)                                                                                          \
@@ -280,7 +290,7 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
       (void)hipGetLastError();                                                                                       \
       return fail("dt_head_mlp_f32: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));               \
     }                                                                                                                \
-    DT_LAUNCH(head_mlp_kernel<NG_>, dim3(blocks), dim3(256), lds_bytes, to_stream(s), a);                   \
+    DT_LAUNCH(head_mlp_kernel<NG_>, dim3(blocks), dim3(kHeadThreads), lds_bytes, to_stream(s), a);                   \
   } while (0)
   if (cin == 64) DT_LAUNCH_HEAD(8); else DT_LAUNCH_HEAD(16);
 #undef DT_LAUNCH_HEAD
