@@ -946,8 +946,11 @@ int dt_cv_mlp_hint_planned_f32(const float* cur, const float* src, const float* 
                                const float* w1pix, const float* w2p, const float* tail, const float* hint_mlp,
                                const float* depth_hint, const float* hint_weights, const float* hint_mask, int hint_h,
                                int hint_w, float* volume, int out_nhwc, int batch, int num_src, int h, int w,
-                               int num_planes, void* plan_scratch, dt_stream_t s) {
+                               int num_planes, void* plan_scratch, int64_t plan_scratch_bytes, dt_stream_t s) {
   DT_REQUIRE(plan_scratch != nullptr, "dt_cv_mlp_hint_planned_f32: null plan scratch (dt_cv_mlp_plan_bytes)");
+  DT_REQUIRE(plan_scratch_bytes >= dt_cv_mlp_plan_bytes(batch, h, w, num_planes),
+             "dt_cv_mlp_hint_planned_f32: plan scratch of %ld bytes, %ld needed for batch=%d h=%d w=%d planes=%d on this device",
+             (long)plan_scratch_bytes, (long)dt_cv_mlp_plan_bytes(batch, h, w, num_planes), batch, h, w, num_planes);
   return mlp_hint_launch(cur, src, params, w1dyn, w1pix, w2p, tail, hint_mlp, depth_hint, hint_weights, hint_mask, hint_h,
                          hint_w, volume, out_nhwc, batch, num_src, h, w, num_planes, plan_scratch, s);
 }

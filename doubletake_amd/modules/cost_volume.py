@@ -401,11 +401,11 @@ class FeatureVolumeManager(CostVolumeManager):
             # cost-aware span plan in front of the kernel (the hint kernel skips views a tile cannot see: units differ in
             # cost); the scratch is a fresh torch allocation on the current stream, like the volume itself
             plan = torch.empty(int(L.dt_cv_mlp_plan_bytes(b, h, w, D)), dtype=torch.uint8, device=dev)
-            self._last_plan = plan  # (diagnostics / tests: [span bounds int32 | unit prices uint16])
+            self._last_plan = plan  # (diagnostics / tests: [span bounds int32 | group totals uint32 | in-group price prefixes uint32])
             _abi.check(L.dt_cv_mlp_hint_planned_f32(
                 _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(pk["w1dyn"]), _abi.ptr(pk["w1pix"]),
                 _abi.ptr(pk["w2p"]), _abi.ptr(pk["tail"]), _abi.ptr(hint_ptr), _abi.ptr(hd), _abi.ptr(hw_),
-                _abi.ptr(hm), H2, W2, _abi.ptr(vol), int(nhwc), b, k, h, w, D, _abi.ptr(plan), stream),
+                _abi.ptr(hm), H2, W2, _abi.ptr(vol), int(nhwc), b, k, h, w, D, _abi.ptr(plan), int(plan.numel()), stream),
                 "dt_cv_mlp_hint_planned_f32")
         elif _impl == "mfma":
             _abi.check(L.dt_cv_mlp_hint_f32(

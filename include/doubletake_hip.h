@@ -31,8 +31,9 @@ typedef void* dt_stream_t; /* hipStream_t */
 /* ABI version: bumped whenever the signature of ANY entry point below changes (not for new entry points alone).
  * Bindings compare it with the version they were written against before the first call: an older .so called with
  * shifted arguments would corrupt device memory instead of failing.  History: 101 round 2; 102 round 3 (depth_planes /
- * channels arguments of dt_cv_lowest_cost_f32, dt_cv_overall_mask_u8, dt_cv_mlp_hint_simple_f32); 103 round 4. */
-#define DT_ABI_VERSION 103
+ * channels arguments of dt_cv_lowest_cost_f32, dt_cv_overall_mask_u8, dt_cv_mlp_hint_simple_f32); 103 round 4;
+ * 104 plan_scratch_bytes argument of dt_cv_mlp_hint_planned_f32. */
+#define DT_ABI_VERSION 104
 int dt_version(void);
 const char* dt_last_error(void);
 /* number of HIP devices visible; <0 on runtime error.  No other call needs it. */
@@ -118,8 +119,9 @@ int dt_cv_mlp_hint_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc
 /* The same call with a COST-AWARE SPAN PLAN in front of the volume kernel (round 4): two small kernels price every (tile, plane)
  * unit by the number of source views it can see (the hint kernel skips the feature contractions of views a tile does not see) and
  * give every wave a span of equal estimated work instead of equal length.  Same volume bit for bit (the plan only moves span
- * boundaries).  plan_scratch: device buffer of dt_cv_mlp_plan_bytes(batch, h, w, num_planes) bytes, owned by the caller, scratch
- * for the duration of the call on stream s. */
+ * boundaries).  plan_scratch: device buffer of at least dt_cv_mlp_plan_bytes(batch, h, w, num_planes) bytes (for the device that
+ * is current at the call), owned by the caller, scratch for the duration of the call on stream s; plan_scratch_bytes: its size,
+ * checked against the requirement (a scratch sized for another shape or device is refused, not overrun). */
 int64_t dt_cv_mlp_plan_bytes(int batch, int h, int w, int num_planes);
 int dt_cv_mlp_hint_planned_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc,
                                const float* params, const float* w1dyn, const float* w1pix,
@@ -127,7 +129,7 @@ int dt_cv_mlp_hint_planned_f32(const float* cur_feats_bchw, const float* src_fea
                                const float* depth_hint_b1HW, const float* hint_weights_b1HW,
                                const float* hint_mask_b1HW, int hint_h, int hint_w, float* volume,
                                int out_nhwc, int batch, int num_src, int h, int w, int num_planes,
-                               void* plan_scratch, dt_stream_t s);
+                               void* plan_scratch, int64_t plan_scratch_bytes, dt_stream_t s);
 /* OPT-IN split-precision variant of dt_cv_mlp_hint_f32 (same reference functions, same arguments except the weights):
  * the two dense contractions run on v_mfma_f32_32x32x16_f16 with every operand split into fp16 hi + lo parts
  * (x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo, fp32 accumulation): fp32-class accuracy (dropped term 2^-22 relative) at 3/16

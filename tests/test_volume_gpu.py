@@ -460,3 +460,39 @@ def test_cost_aware_span_plan_only_moves_boundaries():
             older, younger = work.reshape(blocks, 8)[:, :4], work.reshape(blocks, 8)[:, 4:]
             assert older.std() / older.mean() < 0.06 and younger.std() / younger.mean() < 0.08
             assert np.diff(bounds).max() > np.diff(bounds).min() + 2
+
+
+def test_span_plan_scratch_size_is_checked():
+    """dt_cv_mlp_hint_planned_f32 refuses a plan scratch smaller than dt_cv_mlp_plan_bytes says (a buffer sized for another
+    shape must fail the call, not be overrun): error return with a message, nothing launched, the next good call still works."""
+    import gpu_util as gu
+    from doubletake_amd import _abi
+    from doubletake_amd.modules.cost_volume import FeatureMeshHintVolumeManager
+
+    b, k, h, w, D = 1, 2, 24, 32, 16
+    t = gu.to_dev(syn.volume_inputs(b, k, h, w, 16, 11))
+    m = FeatureMeshHintVolumeManager(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+    gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 3)
+    gu.load_formula_mlp(m.hint_mlp, [3, 12, 12, 1], 4)
+    args, hd = gu.volume_call_args(t), gu.hint_dict(t)
+    L = _abi.lib()
+    need = int(L.dt_cv_mlp_plan_bytes(b, h, w, D))
+    assert need > 0 and int(L.dt_cv_mlp_plan_bytes(0, h, w, D)) == 0
+    good = m(**args, cv_depth_hint_dict=hd)[0].clone()
+    orig = L.dt_cv_mlp_plan_bytes
+
+    class Short:  # the module asks the library for the size: make it allocate one byte less
+        def __getattr__(self, n):
+            return (lambda *a: need - 1) if n == "dt_cv_mlp_plan_bytes" else getattr(L, n)
+
+    real_lib = _abi.lib
+    _abi.lib = lambda: Short()
+    try:
+        with pytest.raises(_abi.DoubletakeHipError, match="plan scratch"):
+            m(**args, cv_depth_hint_dict=hd)
+    finally:
+        _abi.lib = real_lib
+    assert L.dt_cv_mlp_plan_bytes is orig
+    again = m(**args, cv_depth_hint_dict=hd)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(again, good)
