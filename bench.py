@@ -644,6 +644,34 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # a second reference point outside the timed region: one more frame in flight than the default.  The rate goes up (the
+    # conv stacks share the chip better), but the volume kernel's workgroups then take their CUs one by one as other frames'
+    # conv kernels drain, so the HIP events around it measure the schedule, not the kernel -- and a kernel trace, which
+    # serialises the streams, no longer agrees with them (profiles/r4z_streams_probe.txt).  The default stays at two streams.
+    more = None
+    if streams is not None and world == 1 and graphs is None and default_cfg and not args.no_side_legs:
+        n_main = len(events)
+        keep = streams
+        streams = keep + [torch.cuda.Stream(device)]
+        streams[-1].wait_stream(torch.cuda.current_stream(device))
+        for i in range(2 * len(streams)):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize(device)
+        cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
+        t2 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + args.steps + 2 * len(streams) + i, timed=True)
+        torch.cuda.synchronize(device)
+        el2 = time.perf_counter() - t2
+        cvmod.FeatureVolumeManager._event_hook = None
+        ev2 = events[n_main:]
+        del events[n_main:]
+        b2 = [e for tag, e, _ in ev2 if tag == "mlp_begin"]
+        e2 = [e for tag, e, _ in ev2 if tag == "mlp_end"]
+        more = {"streams": len(streams), "value": args.steps * CFG["batch"] / el2, "ms_per_step": el2 / args.steps * 1e3,
+                "dominant_kernel_avg_launch_ms_in_region": float(np.mean([b.elapsed_time(e) for b, e in zip(b2, e2)]))}
+        streams = keep
+
     # reference point outside the driver's timed region: the same steps strictly one after the other on one stream
     single = None
     if streams is not None and world == 1:
@@ -782,6 +810,8 @@ def main():
         if single is not None:
             single["frac_of_mfma_peak_isolated"] = flops / (single["dominant_kernel_avg_launch_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
             result["single_stream"] = single
+        if more is not None:
+            result["one_more_stream"] = more
         if use_dist:
             # self-verifying multi-GPU line: how many ranks RCCL really connected, and which RCCL
             result["config"]["ranks_seen"] = int(dist.get_world_size())
