@@ -55,6 +55,20 @@ def test_bench_other_baseline_shape_prints_the_same_contract():
     assert d["roofline_conv"]["direct_equivalent_flops_per_step"] > 3e11   # 2 frames x (34.6 G + 292.1 G) x (96x128 / 120x160)
 
 
+def test_bench_graph_mode_keeps_the_roofline_bracket():
+    """bench.py --graph: the captured model step must still be cut around the volume kernel (the manager only cuts while an
+    event hook is installed, so bench.py captures with a placeholder) -- otherwise the line would carry no kernel duration."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--graph", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-side-legs"], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "NaN" not in lines[0], lines
+    d = json.loads(lines[0])
+    assert d["config"]["launch"].startswith("hipGraph") and d["config"]["input_sets"] == 1
+    assert 0.3 < d["roofline"]["frac"] < 1.0 and 0.3 < d["roofline"]["avg_launch_ms"] < 2.0
+    assert "one_more_stream" not in d  # (side legs skipped)
+
+
 def test_two_stream_frame_pipelining_is_bit_identical():
     """bench.py --streams 2 runs consecutive keyframes on alternating HIP streams with only the TSDF integrations
     chained by events.  Same frames, same order: depth maps and the fused volume must not change by a bit."""
