@@ -43,6 +43,7 @@ __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : __expf(v) 
 #ifndef DT_HEAD_WAVES
 #define DT_HEAD_WAVES 8
 #endif
+static_assert(DT_HEAD_WAVES % 4 == 0 && DT_HEAD_WAVES >= 4 && DT_HEAD_WAVES <= 16, "whole waves per SIMD");
 constexpr int kHeadThreads = 64 * DT_HEAD_WAVES;
 
 template <int NG>  // NG = cin / 8 input groups (8 or 16)
@@ -67,10 +68,16 @@ __global__ __launch_bounds__(kHeadThreads, 1) void head_mlp_kernel(const HeadArg
   const int half = lane >> 5, p = lane & 31;
   const int lane_off = (half * 32 + p) * 4;
   const long tiles = (a.pixels + 31) / 32;
-  const long waves_total = (long)gridDim.x * DT_HEAD_WAVES;
-  const long wid = (long)blockIdx.x * DT_HEAD_WAVES + wave;
-  long t = wid * tiles / waves_total;
-  const long t_end = (wid + 1) * tiles / waves_total;  // balanced contiguous span of pixel tiles
+  // balanced contiguous spans of pixel tiles, dealt to SIMDs first (wave w of a workgroup runs on SIMD w & 3) and then split
+  // between the waves of a SIMD: with 3072 tiles on 1024 SIMDs every SIMD gets 3 (its waves 2 + 1), where spans balanced per
+  // wave would give the wave pairs 2 + 2 and 1 + 1
+  constexpr int kWavesPerSimd = DT_HEAD_WAVES / 4;
+  const long simds_total = (long)gridDim.x * 4;
+  const long sid = (long)blockIdx.x * 4 + (wave & 3);
+  const long s_begin = sid * tiles / simds_total, s_end = (sid + 1) * tiles / simds_total;
+  const int sub = wave >> 2;
+  long t = s_begin + (s_end - s_begin) * sub / kWavesPerSimd;
+  const long t_end = s_begin + (s_end - s_begin) * (sub + 1) / kWavesPerSimd;
   const float bc = lds_tail[384];
 
   float4 xq[NG], xn[NG];
