@@ -292,8 +292,9 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
     long u, u_end;
     if (a.span_bounds) {  // cost-aware plan (mlp_plan_* below): spans of equal estimated work
       const int* sb = a.span_bounds + (long)lbid * NWAVES + wave;
-      u = sb[0];
-      u_end = sb[1];
+      // (clamped: a scratch that dt_cv_mlp_plan_f32 never filled yields a wrong volume, never an access outside it)
+      u = min(max((long)sb[0], 0L), a.total_units);
+      u_end = min(max((long)sb[1], u), a.total_units);
     } else if (NWAVES == 8 && a.old_share_q16 != 32768) {
       const long g0 = (long)lbid * a.total_units / nblk, g1 = ((long)lbid + 1) * a.total_units / nblk;  // this workgroup's units
       const long cut = g0 + (g1 - g0) * a.old_share_q16 / 65536;                                        // older half | younger half
@@ -861,6 +862,27 @@ int dt_cv_mlp_pack_floats(int num_src, int* w1dyn, int* w1pix, int* w2p, int* ta
   return 0;
 }
 
+// launch geometry of the volume kernel for one call (shared by the plan and the launch, which must agree on it)
+struct MlpGrid {
+  int num_tiles, cus, nw, blocks;
+  long total_units;
+  bool stream, plan;  // plan: the cost-aware span plan applies to the hint kernel of this geometry
+};
+static MlpGrid mlp_grid(int batch, int num_src, int h, int w, int num_planes) {
+  MlpGrid g;
+  g.num_tiles = (int)(((long)h * w + 31) / 32);
+  g.cus = num_cus();
+  g.total_units = (long)batch * g.num_tiles * num_planes;
+  g.stream = num_src > kMaxSrcMfma;  // more views than LDS holds: the further views' fragments come from L2
+  g.nw = g.stream ? 4 : g_mlp_waves;  // streamed views: one wave per SIMD (register room for the loads in flight)
+  const long want = (g.total_units + g.nw - 1) / g.nw;  // at least one unit per wave
+  g.blocks = (int)(want < g.cus ? want : g.cus);
+  // cost-aware span plan: only where units differ in cost (the hint kernel's empty-view skip) and for the tuned instantiation
+  static const bool plan_on = [] { const char* e = getenv("DT_MLP_PLAN"); return !(e && e[0] == '0'); }();
+  g.plan = plan_on && !g.stream && g.nw == 8 && DT_MLP_SKIP_EMPTY && g.total_units < 2147483647L && mlp_plan_groups(g.total_units) < 8000;
+  return g;
+}
+
 static int mlp_hint_launch(const float* cur, const float* src, const float* params, const float* w1dyn,
                            const float* w1pix, const float* w2p, const float* tail, const float* hint_mlp,
                            const float* depth_hint, const float* hint_weights, const float* hint_mask, int hint_h,
@@ -871,39 +893,23 @@ static int mlp_hint_launch(const float* cur, const float* src, const float* para
   DT_REQUIRE(cur && src && params && w1dyn && w1pix && w2p && tail && volume, "dt_cv_mlp_hint_f32: null pointer");
   DT_REQUIRE(hint_mlp == nullptr || (depth_hint && hint_weights && hint_mask && hint_h > 0 && hint_w > 0),
              "dt_cv_mlp_hint_f32: hint MLP given without hint maps");
+  const MlpGrid g = mlp_grid(batch, num_src, h, w, num_planes);
   MlpArgs a;
   a.cur = cur; a.src = src; a.params = params; a.w1dyn = w1dyn; a.w1pix = w1pix; a.w2p = w2p; a.tail = tail;
   a.hint_mlp = hint_mlp; a.hint_d = depth_hint; a.hint_w = hint_weights; a.hint_m = hint_mask;
   a.vol = volume; a.hint_h = hint_h; a.hint_w2 = hint_w; a.out_nhwc = out_nhwc;
   a.B = batch; a.K = num_src; a.h = h; a.w = w; a.D = num_planes;
-  const long hw = (long)h * w;
-  a.num_tiles = (int)((hw + 31) / 32);
+  a.num_tiles = g.num_tiles;
   a.tile_order = mlp_tile_order(h, w, to_stream(s));
-  const int cus = num_cus();
-  a.total_units = (long)batch * a.num_tiles * num_planes;
+  a.total_units = g.total_units;
   static const int old_share = [] { const char* e = getenv("DT_MLP_OLD_SHARE"); const double v = e ? atof(e) : 0.61; return (int)(65536.0 * (v > 0.2 && v < 0.9 ? v : 0.5)); }();
   a.old_share_q16 = old_share;
-  a.span_bounds = nullptr;
-  const int nw = (num_src > kMaxSrcMfma) ? 4 : g_mlp_waves;  // streamed views: one wave per SIMD (register room for the loads in flight)
-  const bool stream = num_src > kMaxSrcMfma;  // more views than LDS holds: the further views' fragments come from L2
+  // spans of equal estimated work, written by dt_cv_mlp_plan_f32 for this geometry (the same predicate decides there)
+  a.span_bounds = (plan_scratch && hint_mlp && g.plan) ? reinterpret_cast<const int*>(plan_scratch) : nullptr;
+  const int nw = g.nw, blocks = g.blocks;
+  const bool stream = g.stream;
   const size_t lds_bytes = (size_t)(mlp_w1dyn_floats(stream ? kMaxSrcMfma : num_src) + kW2Floats + kTailFloats + kHintFloats +
                                     nw * kStageFloats) * sizeof(float);
-  const long want = (a.total_units + nw - 1) / nw;  // at least one unit per wave
-  const int blocks = (int)(want < cus ? want : cus);
-  // cost-aware span plan: only where units differ in cost (the hint kernel's empty-view skip) and for the tuned instantiation
-  static const bool plan_on = [] { const char* e = getenv("DT_MLP_PLAN"); return !(e && e[0] == '0'); }();
-  if (plan_scratch && plan_on && hint_mlp && !stream && nw == 8 && DT_MLP_SKIP_EMPTY && a.total_units < 2147483647L && mlp_plan_groups(a.total_units) < 8000) {
-    int* bounds = reinterpret_cast<int*>(plan_scratch);
-    const int ngroups = (int)mlp_plan_groups(a.total_units);
-    unsigned* gsum = reinterpret_cast<unsigned*>(bounds + mlp_plan_bound_ints(cus));
-    unsigned* pref = gsum + (ngroups + 1) / 2 * 2;
-    DT_LAUNCH(mlp_plan_cost_kernel, dim3((unsigned)ngroups), dim3(256), 0, to_stream(s), params, a.tile_order, pref, gsum, batch,
-              num_src, h, w, num_planes, a.num_tiles, a.total_units);
-    const int nslots = blocks * nw;
-    DT_LAUNCH(mlp_plan_bounds_kernel, dim3((unsigned)((nslots + 1 + 255) / 256)), dim3(256), (size_t)(ngroups + 1) * sizeof(long),
-              to_stream(s), pref, gsum, a.total_units, ngroups, blocks, nw, a.old_share_q16, bounds);
-    a.span_bounds = bounds;
-  }
 #define DT_LAUNCH_MLP(HINT_, NW_, ST_)                                                                             \
   do {                                                                                                             \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cv_mlp_mfma_kernel<HINT_, NW_, ST_>),          \
@@ -942,17 +948,41 @@ int64_t dt_cv_mlp_plan_bytes(int batch, int h, int w, int num_planes) {
   return ((int64_t)mlp_plan_bound_ints(device_cu_count()) + (ngroups + 1) / 2 * 2 + units) * 4;
 }
 
+int dt_cv_mlp_plan_f32(const float* params, int batch, int num_src, int h, int w, int num_planes, void* plan_scratch,
+                       int64_t plan_scratch_bytes, dt_stream_t s) {
+  DT_REQUIRE(params && plan_scratch, "dt_cv_mlp_plan_f32: null pointer");
+  DT_REQUIRE(batch > 0 && h > 0 && w > 0 && num_planes > 0, "dt_cv_mlp_plan_f32: bad extents");
+  DT_REQUIRE(num_src > 0 && num_src <= kMaxSrcStream, "dt_cv_mlp_plan_f32: num_src=%d not in 1..%d", num_src, kMaxSrcStream);
+  DT_REQUIRE(plan_scratch_bytes >= dt_cv_mlp_plan_bytes(batch, h, w, num_planes),
+             "dt_cv_mlp_plan_f32: plan scratch of %ld bytes, %ld needed for batch=%d h=%d w=%d planes=%d on this device",
+             (long)plan_scratch_bytes, (long)dt_cv_mlp_plan_bytes(batch, h, w, num_planes), batch, h, w, num_planes);
+  const MlpGrid g = mlp_grid(batch, num_src, h, w, num_planes);
+  if (!g.plan) return 0;  // (streamed views, the one-wave-per-SIMD build, DT_MLP_PLAN=0: the planned call uses equal-length spans)
+  const int* tile_order = mlp_tile_order(h, w, to_stream(s));
+  static const int old_share = [] { const char* e = getenv("DT_MLP_OLD_SHARE"); const double v = e ? atof(e) : 0.61; return (int)(65536.0 * (v > 0.2 && v < 0.9 ? v : 0.5)); }();
+  int* bounds = reinterpret_cast<int*>(plan_scratch);
+  const int ngroups = (int)mlp_plan_groups(g.total_units);
+  unsigned* gsum = reinterpret_cast<unsigned*>(bounds + mlp_plan_bound_ints(g.cus));
+  unsigned* pref = gsum + (ngroups + 1) / 2 * 2;
+  DT_LAUNCH(mlp_plan_cost_kernel, dim3((unsigned)ngroups), dim3(256), 0, to_stream(s), params, tile_order, pref, gsum, batch,
+            num_src, h, w, num_planes, g.num_tiles, g.total_units);
+  const int nslots = g.blocks * g.nw;
+  DT_LAUNCH(mlp_plan_bounds_kernel, dim3((unsigned)((nslots + 1 + 255) / 256)), dim3(256), (size_t)(ngroups + 1) * sizeof(long),
+            to_stream(s), pref, gsum, g.total_units, ngroups, g.blocks, g.nw, old_share, bounds);
+  return check_launch("dt_cv_mlp_plan_f32");
+}
+
 int dt_cv_mlp_hint_planned_f32(const float* cur, const float* src, const float* params, const float* w1dyn,
                                const float* w1pix, const float* w2p, const float* tail, const float* hint_mlp,
                                const float* depth_hint, const float* hint_weights, const float* hint_mask, int hint_h,
                                int hint_w, float* volume, int out_nhwc, int batch, int num_src, int h, int w,
-                               int num_planes, void* plan_scratch, int64_t plan_scratch_bytes, dt_stream_t s) {
-  DT_REQUIRE(plan_scratch != nullptr, "dt_cv_mlp_hint_planned_f32: null plan scratch (dt_cv_mlp_plan_bytes)");
-  DT_REQUIRE(plan_scratch_bytes >= dt_cv_mlp_plan_bytes(batch, h, w, num_planes),
+                               int num_planes, const void* plan, int64_t plan_bytes, dt_stream_t s) {
+  DT_REQUIRE(plan != nullptr, "dt_cv_mlp_hint_planned_f32: null plan scratch (dt_cv_mlp_plan_f32 / dt_cv_mlp_plan_bytes)");
+  DT_REQUIRE(plan_bytes >= dt_cv_mlp_plan_bytes(batch, h, w, num_planes),
              "dt_cv_mlp_hint_planned_f32: plan scratch of %ld bytes, %ld needed for batch=%d h=%d w=%d planes=%d on this device",
-             (long)plan_scratch_bytes, (long)dt_cv_mlp_plan_bytes(batch, h, w, num_planes), batch, h, w, num_planes);
+             (long)plan_bytes, (long)dt_cv_mlp_plan_bytes(batch, h, w, num_planes), batch, h, w, num_planes);
   return mlp_hint_launch(cur, src, params, w1dyn, w1pix, w2p, tail, hint_mlp, depth_hint, hint_weights, hint_mask, hint_h,
-                         hint_w, volume, out_nhwc, batch, num_src, h, w, num_planes, plan_scratch, s);
+                         hint_w, volume, out_nhwc, batch, num_src, h, w, num_planes, const_cast<void*>(plan), s);
 }
 
 }  // extern "C"

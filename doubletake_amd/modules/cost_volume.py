@@ -281,8 +281,8 @@ class FeatureVolumeManager(CostVolumeManager):
     #: the fp16 matrix pipe, fp32-class accuracy, ~4x less matrix time; csrc/cv_mlp_split.hip).  Set on an instance
     #: (`manager.precision = "split16"`) or for the process with DT_MLP_PRECISION=split16.
     precision = os.environ.get("DT_MLP_PRECISION", "fp32")
-    #: cost-aware span plan in front of the fused hint kernel (dt_cv_mlp_hint_planned_f32): two small launches that give every
-    #: wave a span of equal estimated work; same volume bit for bit.  DT_MLP_PLAN=0 switches it off in the library as well.
+    #: cost-aware span plan in front of the fused hint kernel (dt_cv_mlp_plan_f32 + dt_cv_mlp_hint_planned_f32): two small
+    #: launches that give every wave a span of equal estimated work; same volume (the plan only moves span boundaries).  DT_MLP_PLAN=0 switches it off in the library as well.
     use_span_plan = os.environ.get("DT_MLP_PLAN", "1") != "0"
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=None, matching_dim_size=16,
@@ -386,6 +386,17 @@ class FeatureVolumeManager(CostVolumeManager):
             vol = torch.empty(b, D, h, w, device=dev, dtype=torch.float32, memory_format=torch.channels_last)
         else:
             vol = torch.empty(b, D, h, w, device=dev, dtype=torch.float32)
+        planned = (_impl == "mfma" and self._has_hint and self.use_span_plan
+                   and not (self.precision == "split16" and k <= self.MAX_SPLIT16_VIEWS))
+        plan = None
+        if planned:
+            # cost-aware span plan of the hint kernel (it skips views a tile cannot see: units differ in cost): two small launches
+            # that read only the cameras and planes in `params`, in front of the event bracket of the volume kernel itself.  The
+            # scratch is a fresh torch allocation on the current stream, like the volume
+            plan = torch.empty(int(L.dt_cv_mlp_plan_bytes(b, h, w, D)), dtype=torch.uint8, device=dev)
+            self._last_plan = plan  # (diagnostics / tests: [span bounds int32 | group totals uint32 | in-group price prefixes uint32])
+            _abi.check(L.dt_cv_mlp_plan_f32(_abi.ptr(params), b, k, h, w, D, _abi.ptr(plan), int(plan.numel()), stream),
+                       "dt_cv_mlp_plan_f32")
         hook = FeatureVolumeManager._event_hook
         if hook is not None:
             _graphs.cut("mlp_begin")  # (hipGraph capture: segment boundary so that the hook's events bracket the kernel on
@@ -397,11 +408,7 @@ class FeatureVolumeManager(CostVolumeManager):
                 _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(pk["sp_w1dyn"]), _abi.ptr(pk["sp_w1pix"]),
                 _abi.ptr(pk["sp_w2"]), _abi.ptr(pk["tail"]), _abi.ptr(hint_ptr), _abi.ptr(hd), _abi.ptr(hw_),
                 _abi.ptr(hm), H2, W2, _abi.ptr(vol), int(nhwc), b, k, h, w, D, stream), "dt_cv_mlp_hint_split_f32")
-        elif _impl == "mfma" and self._has_hint and self.use_span_plan:
-            # cost-aware span plan in front of the kernel (the hint kernel skips views a tile cannot see: units differ in
-            # cost); the scratch is a fresh torch allocation on the current stream, like the volume itself
-            plan = torch.empty(int(L.dt_cv_mlp_plan_bytes(b, h, w, D)), dtype=torch.uint8, device=dev)
-            self._last_plan = plan  # (diagnostics / tests: [span bounds int32 | group totals uint32 | in-group price prefixes uint32])
+        elif planned:
             _abi.check(L.dt_cv_mlp_hint_planned_f32(
                 _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(pk["w1dyn"]), _abi.ptr(pk["w1pix"]),
                 _abi.ptr(pk["w2p"]), _abi.ptr(pk["tail"]), _abi.ptr(hint_ptr), _abi.ptr(hd), _abi.ptr(hw_),

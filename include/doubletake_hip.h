@@ -32,8 +32,9 @@ typedef void* dt_stream_t; /* hipStream_t */
  * Bindings compare it with the version they were written against before the first call: an older .so called with
  * shifted arguments would corrupt device memory instead of failing.  History: 101 round 2; 102 round 3 (depth_planes /
  * channels arguments of dt_cv_lowest_cost_f32, dt_cv_overall_mask_u8, dt_cv_mlp_hint_simple_f32); 103 round 4;
- * 104 plan_scratch_bytes argument of dt_cv_mlp_hint_planned_f32. */
-#define DT_ABI_VERSION 104
+ * 104 plan_scratch_bytes argument of dt_cv_mlp_hint_planned_f32; 105 the plan is written by dt_cv_mlp_plan_f32, the planned
+ * call only consumes it. */
+#define DT_ABI_VERSION 105
 int dt_version(void);
 const char* dt_last_error(void);
 /* number of HIP devices visible; <0 on runtime error.  No other call needs it. */
@@ -116,20 +117,27 @@ int dt_cv_mlp_hint_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc
                        const float* hint_mask_b1HW, int hint_h, int hint_w, float* volume,
                        int out_nhwc, int batch, int num_src, int h, int w, int num_planes,
                        dt_stream_t s);
-/* The same call with a COST-AWARE SPAN PLAN in front of the volume kernel (round 4): two small kernels price every (tile, plane)
- * unit by the number of source views it can see (the hint kernel skips the feature contractions of views a tile does not see) and
- * give every wave a span of equal estimated work instead of equal length.  Same volume bit for bit (the plan only moves span
- * boundaries).  plan_scratch: device buffer of at least dt_cv_mlp_plan_bytes(batch, h, w, num_planes) bytes (for the device that
- * is current at the call), owned by the caller, scratch for the duration of the call on stream s; plan_scratch_bytes: its size,
- * checked against the requirement (a scratch sized for another shape or device is refused, not overrun). */
+/* dt_cv_mlp_hint_f32 with a COST-AWARE SPAN PLAN (round 4).  The hint kernel skips the feature contractions of views a pixel
+ * tile cannot see, so its (tile, plane) units differ in cost; dt_cv_mlp_plan_f32 prices every unit by the number of source views
+ * it can see (two small launches that read only `params`, i.e. the cameras and planes) and writes the unit at which every wave's
+ * span of equal estimated work begins; dt_cv_mlp_hint_planned_f32 runs the volume kernel on those spans.  Same volume as
+ * dt_cv_mlp_hint_f32 (the plan only moves span boundaries).  A plan depends on (params, batch, num_src, h, w, num_planes) and
+ * the device: it may be reused for further calls with the same cameras.
+ * plan_scratch: device buffer of at least dt_cv_mlp_plan_bytes(batch, h, w, num_planes) bytes (for the device that is current at
+ * the call), owned by the caller; its size is passed and checked by both calls (a scratch sized for another shape or device is
+ * refused, not overrun).  dt_cv_mlp_hint_planned_f32 must be given a scratch that dt_cv_mlp_plan_f32 filled for the same
+ * arguments earlier on the same stream (or ordered before it); where the plan does not apply (more source views than the kernel
+ * keeps in LDS, DT_MLP_PLAN=0) dt_cv_mlp_plan_f32 launches nothing and the planned call uses equal-length spans. */
 int64_t dt_cv_mlp_plan_bytes(int batch, int h, int w, int num_planes);
+int dt_cv_mlp_plan_f32(const float* params, int batch, int num_src, int h, int w, int num_planes, void* plan_scratch,
+                       int64_t plan_scratch_bytes, dt_stream_t s);
 int dt_cv_mlp_hint_planned_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc,
                                const float* params, const float* w1dyn, const float* w1pix,
                                const float* w2p, const float* tail, const float* hint_mlp,
                                const float* depth_hint_b1HW, const float* hint_weights_b1HW,
                                const float* hint_mask_b1HW, int hint_h, int hint_w, float* volume,
                                int out_nhwc, int batch, int num_src, int h, int w, int num_planes,
-                               void* plan_scratch, int64_t plan_scratch_bytes, dt_stream_t s);
+                               const void* plan, int64_t plan_bytes, dt_stream_t s);
 /* OPT-IN split-precision variant of dt_cv_mlp_hint_f32 (same reference functions, same arguments except the weights):
  * the two dense contractions run on v_mfma_f32_32x32x16_f16 with every operand split into fp16 hi + lo parts
  * (x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo, fp32 accumulation): fp32-class accuracy (dropped term 2^-22 relative) at 3/16
