@@ -605,12 +605,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
           __builtin_amdgcn_wave_barrier();
         }
       }
-#ifdef DT_MLP_TIMING
+#if defined(DT_MLP_TIMING) && DT_MLP_TIMING + 0 >= 2
+      // (level 2 only: a realtime read per plane drains the wave's LDS / scalar queue and slows the launch by ~15 %, which also
+      //  shifts the balance between the two waves of a SIMD; level 1 keeps the begin / end stamps alone)
       if (lane == 0 && wid < 2048 && planes_done < 24) g_mlp_prog[wid * 24 + planes_done] = __builtin_amdgcn_s_memrealtime();
       ++planes_done;
 #endif
     }
-#ifdef DT_MLP_TIMING
+#if defined(DT_MLP_TIMING) && DT_MLP_TIMING + 0 >= 2
     if (t_first == 0) t_first = __builtin_amdgcn_s_memrealtime();
 #endif
     // next task of the span: the following planes of the same tile, else plane 0 of the next tile / batch element
@@ -642,12 +644,22 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
 // with the launch waiting for the last.  Two small kernels in front of the volume kernel give every wave a span of equal
 // estimated WORK instead:
 //   mlp_plan_cost:   one thread per (batch, tile, plane) unit: projects the tile's first, middle and last pixel into every view
-//                    (same arithmetic as the volume kernel) and prices the unit as kPlanFixed + 27 K + 32 x (views seen)
-//                    (MFMAs of layer 2 + metadata steps + the unit's vector work in MFMA equivalents; 32 per visible view)
+//                    (same arithmetic as the volume kernel) and prices the unit as kPlanFixed + 27 K + 24 x (views seen)
+//                    + 200 on the first plane of a tile (layer-2 MFMAs + metadata steps + the unit's vector work in MFMA
+//                    equivalents; the per-view and per-tile prices are fitted to per-unit stamps, see the kernel)
 //   mlp_plan_bounds: one workgroup: prefix sum of the prices, then the unit at which every wave's share begins -- a workgroup gets
 //                    1 / gridDim of the total, its older four waves old_share of that (see the kernel), in equal parts
 // The plan only moves span boundaries: every (pixel, plane) value is computed by the same code whichever wave owns it.
 constexpr int kPlanFixed = 290;
+#ifndef DT_PLAN_VIEW
+#define DT_PLAN_VIEW 24
+#endif
+#ifndef DT_PLAN_TILE
+#define DT_PLAN_TILE 200
+#endif
+#ifndef DT_PLAN_DEPTH
+#define DT_PLAN_DEPTH 0  // (a plane-index term, fitted at -22 for the far end, made the launch slower: 0.726 -> 0.732 ms)
+#endif
 __host__ __device__ inline int mlp_plan_bound_ints(int cus) { return (cus * 8 + 1 + 1) / 2 * 2; }  // (+1 end marker, even count)
 __host__ __device__ inline long mlp_plan_groups(long units) { return (units + 255) / 256; }         // workgroups of the pricing kernel
 
@@ -680,7 +692,10 @@ __global__ __launch_bounds__(256) void mlp_plan_cost_kernel(const float* __restr
         if ((ix > -1.0f) & (ix < (float)w) & (iy > -1.0f) & (iy < (float)h)) seen |= 1 << k;
       }
     }
-    c = (unsigned)(kPlanFixed + 27 * K + 32 * __builtin_popcount(seen));
+    // prices fitted to per-unit stamps of the kernel (scripts/mlp_cost_fit_probe.py, four frames, both waves of a SIMD pair):
+    // a visible view costs 5 % of an all-empty unit (not the 7 % its MFMA count suggests) and the first plane of a tile 0.4 units
+    // more (the plane-invariant contraction)
+    c = (unsigned)(kPlanFixed + 27 * K + DT_PLAN_VIEW * __builtin_popcount(seen) + (d == 0 ? DT_PLAN_TILE : 0) - (DT_PLAN_DEPTH * d) / D);
   }
   unsigned incl = c;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave start / end stamps of one launch of the fused MLP volume kernel at cfg2 (library built with -DDT_MLP_TIMING:
+"""Per-wave start / end stamps of one launch of the fused MLP volume kernel at cfg2 (library built with -DDT_MLP_TIMING=2:
 DOUBLETAKE_HIP_LIB=doubletake_amd/_lib/variants/timing.so).  Shows how evenly the 2048 resident waves finish."""
 import ctypes
 import json
