@@ -657,6 +657,9 @@ constexpr int kPlanFixed = 290;
 #ifndef DT_PLAN_TILE
 #define DT_PLAN_TILE 200
 #endif
+#ifndef DT_PLAN_PAIR_ROUNDING
+#define DT_PLAN_PAIR_ROUNDING 1  // younger waves' boundaries compensate the rounding of their SIMD partners' (0 = independent targets)
+#endif
 #ifndef DT_PLAN_DEPTH
 #define DT_PLAN_DEPTH 0  // (a plane-index term, fitted at -22 for the far end, made the launch slower: 0.726 -> 0.732 ms)
 #endif
@@ -749,25 +752,9 @@ __global__ __launch_bounds__(256) void mlp_plan_bounds_kernel(const unsigned* __
   const long nslots = (long)nblk * nwaves;
   const long j = (long)blockIdx.x * 256 + t;
   if (j > nslots) return;
-  // cumulative price at which slot j begins: workgroup blk gets 1 / nblk of the total (remainder spread over the first ones),
-  // inside it the older four waves old_share of that in equal parts, the younger four the rest
-  long target;
-  if (j == nslots) {
-    target = total;
-  } else {
-    const long blk = j / nwaves;
-    const int wv = (int)(j - blk * nwaves);
-    const long share = total / nblk, rem = total - share * nblk;
-    const long b0 = blk * share + min(blk, rem), b1 = b0 + share + (blk < rem ? 1 : 0);
-    if (nwaves == 8) {
-      const long cut = b0 + (((b1 - b0) * old_share_q16) >> 16);
-      target = (wv < 4) ? b0 + (((cut - b0) * wv) >> 2) : cut + (((b1 - cut) * (wv - 4)) >> 2);
-    } else {
-      target = b0 + (b1 - b0) * wv / nwaves;
-    }
-  }
-  int out = 0;
-  if (target > 0) {
+  // number of units whose cumulative price stays below `target` = the unit boundary behind the unit that reaches it
+  auto bound_at = [&](long target) -> int {
+    if (target <= 0) return 0;
     // group whose cumulative range (gpre[g], gpre[g + 1]] holds the target, then the unit inside it
     int lo = 0, hi = ngroups - 1;
     while (lo < hi) {
@@ -781,7 +768,40 @@ __global__ __launch_bounds__(256) void mlp_plan_bounds_kernel(const unsigned* __
       const int mid = (a + c) >> 1;
       if ((long)pref[ubase + mid] >= in_group) c = mid; else a = mid + 1;
     }
-    out = (int)(ubase + a + 1);  // the span begins behind the unit that reaches the target
+    return (int)(ubase + a + 1);
+  };
+  auto price_upto = [&](int i) -> long { return i <= 0 ? 0L : gpre[(i - 1) >> 8] + (long)pref[i - 1]; };  // cumulative price of units [0, i)
+  // cumulative price at which slot j begins: workgroup blk gets 1 / nblk of the total (remainder spread over the first ones),
+  // inside it the older four waves old_share of that in equal parts, the younger four the rest
+  int out;
+  if (j == nslots) {
+    out = bound_at(total);
+  } else {
+    const long blk = j / nwaves;
+    const int wv = (int)(j - blk * nwaves);
+    const long share = total / nblk, rem = total - share * nblk;
+    const long b0 = blk * share + min(blk, rem), b1 = b0 + share + (blk < rem ? 1 : 0);
+    if (nwaves == 8) {
+      const long cut = b0 + (((b1 - b0) * old_share_q16) >> 16);
+      if (wv <= 4 || !DT_PLAN_PAIR_ROUNDING) {
+        out = bound_at((wv < 4) ? b0 + (((cut - b0) * wv) >> 2) : cut + (((b1 - cut) * (wv - 4)) >> 2));
+      } else {
+        // Units are indivisible (a wave has ~20), so every boundary above is off its target by up to a unit and the summed price of
+        // a SIMD pair (waves w and w + 4) scattered by 1.6 % rms -- +5 % for the unluckiest of 1024 pairs, which the launch waits
+        // for.  The younger waves' boundaries therefore aim at what their OLDER partners really got: pair w should end up with a
+        // quarter of what the workgroup really holds, and the boundary is the unit edge NEAREST to that (round 4, last pass).
+        const int B0 = bound_at(b0), B4 = bound_at(cut), B8 = bound_at(b1);
+        const int Bw = bound_at(b0 + (((cut - b0) * (wv - 4)) >> 2));  // first unit of older wave wv - 4
+        const long W = price_upto(B8) - price_upto(B0), older_so_far = price_upto(Bw) - price_upto(B0);
+        const long target4 = 4 * price_upto(B4) + (long)(wv - 4) * W - 4 * older_so_far;  // 4 x the cumulative price to reach
+        int hi_b = bound_at((target4 + 3) >> 2);
+        hi_b = min(max(hi_b, B4), B8);
+        const int lo_b = max(hi_b - 1, B4);
+        out = (4 * price_upto(hi_b) - target4 <= target4 - 4 * price_upto(lo_b)) ? hi_b : lo_b;
+      }
+    } else {
+      out = bound_at(b0 + (b1 - b0) * wv / nwaves);
+    }
   }
   bounds[j] = out;
 }
