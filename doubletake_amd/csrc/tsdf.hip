@@ -142,7 +142,8 @@ struct TsdfConsts {
 
 // DEPTH32: the depth maps are fp32 and rounded to half on the fly (what OurFuser.fuse_frames's .half() does,
 // tools/fusers_helper.py:67-73, without a converting copy kernel in front of every integration)
-template <bool DEPTH32>
+constexpr int kTsdfBallotMinFrames = 3;  // multi-frame calls of at least this many frames pre-select their frames per wave (below)
+template <bool DEPTH32, bool PRESELECT>
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restrict__ values, uint16_t* __restrict__ weights,
                                                             uint32_t* __restrict__ active, int X, int Y, int Z,
                                                             const void* __restrict__ depth_any, int img_h, int img_w,
@@ -159,26 +160,57 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
   const unsigned slab = (unsigned)Y * (unsigned)Z;
   const unsigned pidx = blockIdx.x * blockDim.x + threadIdx.x;
   const float cx = rh(c.origin[0] + (float)i * c.voxel_size);
+  const int lane = threadIdx.x & 63;
+  // Which frames can touch this wave at all?  Frame f0 + l is tested in lane l, one ballot per 64 frames; the frame loop below
+  // then visits the set bits only (ascending = frame order).  A multi-frame call used to repeat the box test of EVERY frame in
+  // every wave of a slab inside any frame's x-range -- half of the launch's instructions (round 4: 243 M vector + 340 M scalar
+  // wave-instructions for 16 frames at 0.02 m).  First the x test alone, before any per-lane index arithmetic:
+  // (PRESELECT = false: one or two frames -- the per-keyframe call of the drivers -- where the plain scalar walk over the frames
+  //  is cheaper than the pre-pass; the host picks the instantiation)
+  constexpr bool few = !PRESELECT;
   bool any_x = false;
-  for (int f = 0; f < num_frames; ++f) {
-    const float* fp = fp_all + (size_t)f * kFrameParams;
-    any_x |= (cx > fp[12] && cx < fp[15]);
+  if (few) {
+    for (int f = 0; f < num_frames; ++f) {
+      const float* fp = fp_all + (size_t)f * kFrameParams;
+      any_x |= (cx > fp[12] && cx < fp[15]);
+    }
+  } else {
+    for (int f0 = 0; f0 < num_frames; f0 += 64) {
+      const int f = f0 + lane;
+      bool hx = false;
+      if (f < num_frames) {
+        const float* fp = fp_all + (size_t)f * kFrameParams;
+        hx = cx > fp[12] && cx < fp[15];
+      }
+      any_x |= __ballot(hx) != 0ull;
+    }
   }
   if (!any_x) return;
   const size_t id = (size_t)i * slab + pidx;
   bool is_active = false;
-  if (pidx < slab) {
+  if (pidx < slab) {  // (slab is a multiple of 64: a wave is inside it with all 64 lanes or not at all)
     const int j = (int)(pidx / (unsigned)Z);
     const int k = (int)(pidx - (unsigned)j * (unsigned)Z);
     // voxel centre: half(fp32(origin) + idx * vs)   (tools/tsdf.py:144-148,164)
     const float cy = rh(c.origin[1] + (float)j * c.voxel_size);
     const float cz = rh(c.origin[2] + (float)k * c.voxel_size);
+    // the wave's own extent in y and z (pidx runs z-fastest: j is non-decreasing over the lanes; a wave that spans two rows
+    // may hold any z), a conservative stand-in for the per-voxel test that every visited frame still makes exactly
+    float cy_lo = 0.f, cy_hi = 0.f, cz_lo = 0.f, cz_hi = 0.f;
+    if (!few) {
+      cy_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cy)));
+      cy_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cy), 63));
+      const bool one_row = __builtin_amdgcn_readfirstlane(j) == __builtin_amdgcn_readlane(j, 63);
+      cz_lo = one_row ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cz))) : rh(c.origin[2]);
+      cz_hi = one_row ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cz), 63))
+                      : rh(c.origin[2] + (float)(Z - 1) * c.voxel_size);
+    }
     bool loaded = false, dirty = false;
     float cur_v = 0.f, cur_w = 0.f;
-    for (int f = 0; f < num_frames; ++f) {
+    auto integrate_frame = [&](const int f) {
       const float* fp = fp_all + (size_t)f * kFrameParams;
       const bool inside = cx > fp[12] && cx < fp[15] && cy > fp[13] && cy < fp[16] && cz > fp[14] && cz < fp[17];
-      if (!inside) continue;
+      if (!inside) return;
       float q[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
@@ -224,6 +256,18 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
         cur_w = rh(fminf(tot, 1.0f));
         dirty = true;
       }
+    };
+    if (few) {
+      for (int f = 0; f < num_frames; ++f) integrate_frame(f);
+    } else {
+      for (int f0 = 0; f0 < num_frames; f0 += 64) {
+        bool hit = false;
+        if (f0 + lane < num_frames) {
+          const float* fpl = fp_all + (size_t)(f0 + lane) * kFrameParams;
+          hit = cx > fpl[12] && cx < fpl[15] && cy_hi > fpl[13] && cy_lo < fpl[16] && cz_hi > fpl[14] && cz_lo < fpl[17];
+        }
+        for (unsigned long long todo = __ballot(hit); todo != 0ull; todo &= todo - 1ull) integrate_frame(f0 + (int)__builtin_ctzll(todo));
+      }
     }
     if (dirty) {
       values[id] = f2h(cur_v);
@@ -233,7 +277,6 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(uint16_t* __restric
   // active bitmap: bit id of word id>>5.  A wave covers 64 consecutive ids = two whole words
   // (blockDim is a multiple of 64 and the grid is linear), so one lane per word does a plain OR.
   const unsigned long long bal = __ballot(is_active);
-  const int lane = threadIdx.x & 63;
   if (bal != 0ull && (lane == 0 || lane == 32)) {
     const uint32_t bits = (lane == 0) ? (uint32_t)(bal & 0xffffffffull) : (uint32_t)(bal >> 32);
     const size_t word = (id >> 5);
@@ -380,12 +423,16 @@ static int integrate_frames(uint16_t* values, uint16_t* weights, uint32_t* activ
              x_begin + x_count, X);
   if (x_count == 0) return 0;
   const dim3 grid((unsigned)((slab + 255) / 256), (unsigned)x_count);
-  if (depth32)
-    DT_LAUNCH(tsdf_integrate_kernel<true>, grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, img_h,
-                       img_w, frame_params, num_frames, c, x_begin);
-  else
-    DT_LAUNCH(tsdf_integrate_kernel<false>, grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, img_h,
-                       img_w, frame_params, num_frames, c, x_begin);
+  const bool preselect = num_frames >= kTsdfBallotMinFrames;
+#define DT_LAUNCH_TSDF(D32_, PRE_)                                                                                          \
+  DT_LAUNCH((tsdf_integrate_kernel<D32_, PRE_>), grid, dim3(256), 0, to_stream(s), values, weights, active, X, Y, Z, depth, \
+            img_h, img_w, frame_params, num_frames, c, x_begin)
+  if (depth32) {
+    if (preselect) DT_LAUNCH_TSDF(true, true); else DT_LAUNCH_TSDF(true, false);
+  } else {
+    if (preselect) DT_LAUNCH_TSDF(false, true); else DT_LAUNCH_TSDF(false, false);
+  }
+#undef DT_LAUNCH_TSDF
   return check_launch("dt_tsdf_integrate_f16");
 }
 
