@@ -3,8 +3,10 @@ of scope: SURVEY.md section 2)."""
 from __future__ import annotations
 
 import importlib
+import io
 import pickle
 import types
+import zipfile
 
 import torch
 
@@ -71,13 +73,30 @@ class _StateDictUnpickler(pickle.Unpickler):
         return _placeholder_class(module, name)
 
 
-_state_dict_pickle = types.SimpleNamespace(Unpickler=_StateDictUnpickler, load=pickle.load, loads=pickle.loads,
+def _restricted_load(f, **kw):
+    return _StateDictUnpickler(f, **kw).load()
+
+
+def _restricted_loads(b, **kw):
+    return _StateDictUnpickler(io.BytesIO(b), **kw).load()
+
+
+# torch.load's legacy (non-zip) reader calls ``pickle_module.load(f)`` directly for the magic number, protocol version,
+# sys_info and storage keys, before and after it uses ``pickle_module.Unpickler``: EVERY entry point of the namespace
+# therefore goes through the restricted unpickler (a file holding a bare ``pickle.dumps(obj)`` with a hostile
+# ``__reduce__`` would otherwise run its callable before "Invalid magic number" is raised).
+_state_dict_pickle = types.SimpleNamespace(Unpickler=_StateDictUnpickler, load=_restricted_load, loads=_restricted_loads,
                                            __name__="doubletake_amd.state_dict_pickle")
 
 
 def read_checkpoint_state_dict(path):
     """``state_dict`` of a checkpoint file written by the reference (Lightning ``.ckpt``) or by ``torch.save`` of a
     plain state dict; tensors on the CPU.  Foreign objects in the file are never instantiated (see above)."""
+    if zipfile.is_zipfile(path):
+        with zipfile.ZipFile(path) as z:
+            if any(n.endswith("/constants.pkl") or n == "constants.pkl" for n in z.namelist()):
+                # torch.load would dispatch such an archive to torch.jit.load (code in the file); never a state dict
+                raise RuntimeError(f"{path}: TorchScript archive, not a checkpoint with a state_dict")
     ckpt = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_state_dict_pickle)
     state = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
     if not isinstance(state, dict) or not all(isinstance(v, torch.Tensor) for v in state.values()):

@@ -193,3 +193,52 @@ def test_lightning_style_checkpoint_with_foreign_hyper_parameters_loads(tmp_path
     torch.save({"state_dict": {"a": 1}}, tmp_path / "bad.pt")
     with pytest.raises(RuntimeError):
         mu.read_checkpoint_state_dict(tmp_path / "bad.pt")
+
+
+def test_legacy_format_hostile_pickle_never_runs_its_reduce_callable(tmp_path):
+    """torch's legacy (non-zip) reader calls ``pickle_module.load`` directly -- for the magic number,
+    protocol version, sys_info, storage keys -- so every entry point of the pickle namespace handed to ``torch.load``
+    must be the restricted unpickler.  A file that is just ``pickle.dumps(obj)`` with a hostile ``__reduce__`` must be
+    rejected without the callable having run; a legacy-format checkpoint and a TorchScript-looking zip behave as stated."""
+    import pickle
+    import zipfile
+
+    import torch
+
+    from doubletake_amd.utils import model_utils as mu
+
+    marker = tmp_path / "executed.txt"
+
+    class Hostile:
+        def __reduce__(self):
+            import pathlib
+
+            return (pathlib.Path.write_text, (pathlib.Path(str(marker)), "ran"))
+
+    bad = tmp_path / "hostile.ckpt"
+    bad.write_bytes(pickle.dumps(Hostile()))
+    with pytest.raises(Exception):
+        mu.read_checkpoint_state_dict(bad)
+    assert not marker.exists(), "a reduce callable of the file was executed"
+    # the same object hidden behind a valid legacy header (magic number, protocol, sys_info, then the payload)
+    bad2 = tmp_path / "hostile_legacy.ckpt"
+    with open(bad2, "wb") as f:
+        pickle.dump(0x1950A86A20F9469CFC6C, f, protocol=2)
+        pickle.dump(1001, f, protocol=2)
+        pickle.dump(Hostile(), f, protocol=2)
+    with pytest.raises(Exception):
+        mu.read_checkpoint_state_dict(bad2)
+    assert not marker.exists(), "a reduce callable of the file was executed"
+    # an honest legacy-format file (torch.save(..., _use_new_zipfile_serialization=False)) still loads
+    sd = {"a.weight": torch.arange(6.0).view(2, 3), "a.bias": torch.ones(2)}
+    legacy = tmp_path / "legacy.pt"
+    torch.save({"state_dict": sd}, legacy, _use_new_zipfile_serialization=False)
+    got = mu.read_checkpoint_state_dict(legacy)
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    # a zip that torch.load would hand to torch.jit.load is refused before torch.load sees it
+    ts = tmp_path / "script.pt"
+    with zipfile.ZipFile(ts, "w") as z:
+        z.writestr("archive/constants.pkl", b"\x80\x02)." )
+        z.writestr("archive/data.pkl", b"\x80\x02}.")
+    with pytest.raises(RuntimeError, match="TorchScript"):
+        mu.read_checkpoint_state_dict(ts)
