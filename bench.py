@@ -63,8 +63,31 @@ CONFIGS = {
 }
 ENC_WIDTHS = {"resnet18d": [64, 64, 128, 256, 512], "efficientnet": [24, 48, 64, 160, 256]}
 CFG = dict(CONFIGS["cfg2_small"])
+DEFAULT_STREAMS = 4   # keyframes in flight (round 5: 742 frames/s at 4 against 700 at 2 and 730 at 3, profiles/r4z_streams_probe.txt)
+HW_QUEUES = "8"       # GPU_MAX_HW_QUEUES for the process: the HIP runtime's default of four hardware queues makes a fifth stream
+                      # (4 model streams + the default one) share a queue with a model stream (647 instead of 742 frames/s)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)" = "Peak FP32 (vector)"
+DOT_ISSUE_SLOTS_PER_WAVE_SAMPLE = 201  # cv_dot_lds_kernel staged path, ISA count: 121 plain + 40 packed (x2) vector instructions
 PEAK_LDS_TBPS = 256 * 256 * 2.4e9 / 1e12  # 256 CUs x 256 B/clk (ds_read_b128, same guide, LDS table) x 2.4 GHz = 157 TB/s
+
+
+# Every default-config line carries these keys, whatever the GPU count: objects that are only measured on rank 0 at N = 1 (the CPU
+# leg, the side legs after the timed region) are null on an N > 1 line, with the reason in `null_because` (the
+# first SCALE line must not lack a key the N = 1 line has).
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config", "roofline", "roofline_conv", "single_stream", "other_stream_counts", "roofline_warp_match_dot",
+             "roofline_tsdf", "end_to_end", "roofline_encoder", "parity", "cpu_baseline")
+
+
+def complete_line(result, world, why_n1="measured on rank 0 at N=1 only (python bench.py --gpus 1)"):
+    """Fill the keys of LINE_KEYS that this run did not measure with null and say why (returns the same dict)."""
+    missing = [k for k in LINE_KEYS if k not in result]
+    for k in missing:
+        result[k] = None
+    if missing:
+        result["null_because"] = {k: (why_n1 if world > 1 else "skipped by a command-line flag of this run (--no-side-legs / "
+                                                                "--no-cpu-baseline / --streams 1 / --graph)") for k in missing}
+    return result
 
 
 def volume_flops(b, k, h, w, D):
@@ -240,7 +263,7 @@ def dot_volume_roofline(device, t, launches=30):
         #   LDS : the tap bytes, against 256 B/clk/CU conflict-free ds_read_b128 bandwidth
         valu_flops = 186.0 * b * h * w * D * k
         t_s = ms * 1e-3
-        return {"avg_launch_ms": ms, "achieved": algo / t_s / 1e9, "frac": algo / t_s / 1e9 / 8000.0,
+        return {"samples": float(b) * h * w * D * k, "avg_launch_ms": ms, "achieved": algo / t_s / 1e9, "frac": algo / t_s / 1e9 / 8000.0,
                 "algorithmic_bytes_per_launch": algo, "bilinear_tap_bytes_per_launch": taps, "tap_GBps": taps / t_s / 1e9,
                 "valu_frac": valu_flops / t_s / 1e12 / PEAK_F32_MFMA_TFLOPS, "lds_frac": taps / t_s / 1e12 / PEAK_LDS_TBPS}
 
@@ -252,7 +275,24 @@ def dot_volume_roofline(device, t, launches=30):
     return {
         "kernel": "cv_dot_lds_kernel (CostVolumeManager: warp + dot-product match with LDS-staged source footprints; "
                   "not on the DoubleTake path)",
+        # The north star asks for this kernel's fraction of the HBM roofline; `achieved` / `frac` answer that as defined.  What
+        # BOUNDS the kernel is vector-instruction issue: see `bound_by` below.
         "bound": "hbm", "achieved": main["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": main["frac"], "traffic": None,
+        "bound_by": "valu",
+        "bound_statement": {
+            "hbm_time_floor_ms": main["algorithmic_bytes_per_launch"] / 8.0e12 * 1e3,
+            # ISA count of the staged path: 121 plain + 40 packed fp32 (2 issue slots each) vector instructions per wave-sample
+            # besides 16 ds_read_b128; 4 cycles per issue slot per SIMD, 1024 SIMDs, 2.4 GHz
+            "valu_issue_floor_ms": (main["samples"] / 64.0) * DOT_ISSUE_SLOTS_PER_WAVE_SAMPLE * 4.0 / (1024 * 2.4e9) * 1e3,
+            "issue_slots_per_wave_sample": DOT_ISSUE_SLOTS_PER_WAVE_SAMPLE,
+            "max_hbm_frac_at_valu_floor": (main["algorithmic_bytes_per_launch"] / 8.0e12) /
+                                          ((main["samples"] / 64.0) * DOT_ISSUE_SLOTS_PER_WAVE_SAMPLE * 4.0 / (1024 * 2.4e9)),
+            "frac_of_valu_issue_floor": ((main["samples"] / 64.0) * DOT_ISSUE_SLOTS_PER_WAVE_SAMPLE * 4.0 / (1024 * 2.4e9) * 1e3) / main["avg_launch_ms"],
+            "text": "compulsory HBM traffic of the dot-product volume (inputs once + volume once) is microseconds of HBM time, below a "
+                    "kernel launch; every (pixel, plane, view) sample costs a projection, a bilinear tap set and 4 x 16 multiply-adds "
+                    "on the vector ALU.  At the instruction count of this formulation the issue floor alone caps the reachable HBM "
+                    "fraction at max_hbm_frac_at_valu_floor: the north star's 0.40 cannot be met by any schedule of this arithmetic",
+        },
         "algorithmic_bytes_per_launch": main["algorithmic_bytes_per_launch"],
         "bilinear_tap_bytes_per_launch": main["bilinear_tap_bytes_per_launch"], "tap_GBps": main["tap_GBps"],
         "avg_launch_ms": main["avg_launch_ms"],
@@ -369,15 +409,26 @@ def tsdf_roofline(device):
     return out
 
 
-def end_to_end(device, t, pyr_t, model, frames=40):
+def encoder_flops_per_image(H, W, c_out=16):
+    """Direct-convolution FLOPs (2 x MAC) of ResnetMatchingEncoder on one H x W image (reference modules/networks.py:138-189):
+    conv1 7x7/2 3->64 at H/2 x W/2, layer1 = four 3x3 64->64 convs at H/4 x W/4, 1x1 64->128, 3x3 128->c_out."""
+    p2, p4 = (H // 2) * (W // 2), (H // 4) * (W // 4)
+    return 2.0 * (147 * 64 * p2 + 4 * 576 * 64 * p4 + 64 * 128 * p4 + 1152 * c_out * p4)
+
+
+def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1):
     """Frames/s of the reference entry point ``model("test", cur_data, src_data)`` INCLUDING the HIP matching encoder
     (ResnetMatchingEncoder, reference modules/networks.py:138-189) on the 1 + K images of every keyframe -- the step just
     before the volume that the headline (forward_from_features) leaves outside.  Image-prior encoder: out of scope (a
     resident synthetic pyramid stands in).  Two modes: "cache_off" = all 1 + K images through the encoder every frame (the
     reference's behaviour); "cache_on" = the cross-frame feature cache (only the new keyframe is encoded; sliding window of
-    sources as in a scan).  Wall clock over `frames` keyframes on one stream, no host synchronisation inside the loop."""
+    sources as in a scan; entries carry a ready event, so a keyframe on another stream orders itself behind the pass that
+    produced its sources).  Wall clock over `frames` keyframes, no host synchronisation inside the loop; reported on one stream
+    and with the headline's number of keyframes in flight (independent keyframes, round-robin over the streams).
+    Also returns `roofline_encoder`: the matching encoder alone (HIP events around the module call, untimed legs)."""
     import torch
     import torch.nn as nn
+    from doubletake_amd import _abi
     from doubletake_amd.utils import synthetic as syn
 
     class FixedPyramid(nn.Module):
@@ -389,7 +440,7 @@ def end_to_end(device, t, pyr_t, model, frames=40):
             return self.pyr
 
     if model.matching_model is None:
-        return None
+        return None, None
     H, W, k_src = CFG["image_h"], CFG["image_w"], CFG["num_src"]
     prev_enc = model.encoder
     model.encoder = FixedPyramid(pyr_t)
@@ -407,31 +458,61 @@ def end_to_end(device, t, pyr_t, model, frames=40):
         data.append((cur, src))
     hint = {nm: t[nm] for nm in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
     res = {"entry_point": 'model("test", cur_data, src_data): matching encoder on 1+K images + volume + CVEncoder + decoder',
-           "frames": frames, "streams": 1}
+           "frames": frames}
     prev_cache = getattr(model, "use_feature_cache", False)
+    side = [torch.cuda.Stream(device) for _ in range(n_streams)] if n_streams > 1 else None
     try:
-        for mode, cache in (("cache_off", False), ("cache_on", True)):
-            model.matching_feature_cache.clear()
-            model.use_feature_cache = cache
+        for ns, streams in ((1, None),) + (((n_streams, side),) if side else ()):
+            leg = {}
+            for mode, cache in (("cache_off", False), ("cache_on", True)):
+                model.matching_feature_cache.clear()
+                model.use_feature_cache = cache
 
-            def run(lo, hi):
-                for f in range(lo, hi):
-                    cur, src = data[f]
-                    cur = dict(cur, **hint)
-                    model("test", cur, dict(src), return_mask=True)
+                def run(lo, hi):
+                    for f in range(lo, hi):
+                        cur, src = data[f]
+                        cur = dict(cur, **hint)
+                        if streams is None:
+                            model("test", cur, dict(src), return_mask=True)
+                        else:
+                            with torch.cuda.stream(streams[f % len(streams)]):
+                                model("test", cur, dict(src), return_mask=True)
 
-            run(0, 8)
-            torch.cuda.synchronize(device)
-            t0 = time.perf_counter()
-            run(8, n)
-            torch.cuda.synchronize(device)
-            dt = time.perf_counter() - t0
-            res[mode] = {"frames_per_s": frames / dt, "ms_per_frame": dt / frames * 1e3}
+                if streams is not None:
+                    for st in streams:
+                        st.wait_stream(torch.cuda.current_stream(device))
+                run(0, 8)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                run(8, n)
+                torch.cuda.synchronize(device)
+                dt = time.perf_counter() - t0
+                leg[mode] = {"frames_per_s": frames / dt, "ms_per_frame": dt / frames * 1e3}
+            if ns == 1:
+                res["streams"] = 1
+                res.update(leg)
+            else:
+                res[f"streams_{ns}"] = leg
+        # the matching encoder alone: 1 + K images in one pass (cache off) and one image (cache on / incremental mode)
+        L = _abi.lib()
+        enc = {"kernels": "stem_conv (7x7/2 + bn + relu) + maxblur + 4 x conv_wino (layer1) + conv 1x1 + instnorm (+LeakyReLU) + "
+                          "conv 3x3 replicate + instnorm (ResnetMatchingEncoder, reference modules/networks.py:138-189)",
+               "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS}
+        for tag, nimg in (("batched_1_plus_K", 1 + k_src), ("single_image", 1)):
+            batch = images[:nimg]
+            c0 = int(L.dt_kernel_launch_count())
+            model.matching_model(batch)
+            launches = int(L.dt_kernel_launch_count()) - c0
+            ms = _event_ms(lambda: model.matching_model(batch), device, 20, 5, gpu_behind_ms=6.0)
+            fl = encoder_flops_per_image(H, W, int(model.matching_model.num_ch_out)) * nimg
+            enc[tag] = {"images": nimg, "direct_equivalent_flops": fl, "avg_ms": ms, "launches": launches,
+                        "achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        enc["achieved"], enc["frac"] = enc["batched_1_plus_K"]["achieved"], enc["batched_1_plus_K"]["frac"]
     finally:
         model.use_feature_cache = prev_cache
         model.encoder = prev_enc
         model.matching_feature_cache.clear()
-    return res
+    return res, enc
 
 
 def self_launch(n):
@@ -479,9 +560,17 @@ def main():
     ap.add_argument("--conv-precision", choices=("fp32", "split16"), default="fp32",
                     help="arithmetic of the 3x3 stride-1 conv layers: exact fp32 MFMA (default, the headline) or the opt-in "
                          "split-precision Winograd kernel (fp16 hi/lo products on the fp16 matrix pipe, fp32 accumulation)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=DEFAULT_STREAMS,
                     help="run consecutive keyframes on this many HIP streams (frames are independent in this workload; the "
-                         "TSDF integrations stay in frame order)")
+                         "TSDF integrations stay in frame order).  The dominant kernel's roofline figure comes from the "
+                         "single-stream leg of the same run (with several frames in flight an event bracket measures the schedule)")
+    ap.add_argument("--tsdf-mode", choices=("replica", "slab"), default="replica",
+                    help="TSDF fusion of the gathered frames: every rank integrates all of them into a whole replica volume "
+                         "(default), or only into its x-slab of the volume, completed by one all_gather of the slabs at the end "
+                         "of the timed region (KeyframeShardFuser(mode='slab'); pays with large volumes: --tsdf-res 0.02)")
+    ap.add_argument("--tsdf-res", type=float, default=0.04,
+                    help="voxel size of the bench's TSDF volume over the 8 x 8 x 3.2 m room (0.04 = the drivers' hint volume, "
+                         "0.02 = their final volume)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the model part of the step from hipGraphs (model.enable_hip_graphs; one graph set per stream) "
                          "instead of ~50 eager launches per keyframe")
@@ -500,6 +589,8 @@ def main():
     CFG.update(CONFIGS[args.config])
     default_cfg = args.config == "cfg2_small"
 
+    if args.streams > 3:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", HW_QUEUES)  # read when the HIP runtime initialises: before torch is imported
     import torch
     import torch.distributed as dist
 
@@ -554,8 +645,8 @@ def main():
 
         room = dict(xmin=-4.0, xmax=4.0, ymin=-4.0, ymax=4.0, zmin=0.0, zmax=3.2)
         H2, W2 = CFG["image_h"] // 2, CFG["image_w"] // 2
-        fuser = KeyframeShardFuser(device, world, rank, (H2, W2), fuser=OurFuser(None, 0.04, 3.0, bounds=room),
-                                   force_collective=args.force_dist)
+        fuser = KeyframeShardFuser(device, world, rank, (H2, W2), fuser=OurFuser(None, args.tsdf_res, 3.0, bounds=room),
+                                   force_collective=args.force_dist, mode=args.tsdf_mode)
         POOL = 64
         _, Kp, Tp = syn.tsdf_frames(POOL, H2, W2, seed=5, bounds=room)
         K_pool16 = torch.from_numpy(Kp).to(device).half()
@@ -656,6 +747,12 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, timed=True)
+    if fuser is not None and args.tsdf_mode == "slab":
+        # slab mode: the replicas are completed by ONE gather of the x-slabs per pass -- inside the timed region, so that the
+        # mode is charged for it (on the stream that ran the last integration)
+        last = streams[(args.warmup + args.steps - 1) % len(streams)] if streams is not None else torch.cuda.current_stream(device)
+        with torch.cuda.stream(last):
+            fuser.gather_slabs()
     torch.cuda.synchronize(device)
     if use_dist:
         dist.barrier()
@@ -668,56 +765,61 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # a second reference point outside the timed region: one more frame in flight than the default.  The rate goes up (the
-    # conv stacks share the chip better), but the volume kernel's workgroups then take their CUs one by one as other frames'
-    # conv kernels drain, so the HIP events around it measure the schedule, not the kernel -- and a kernel trace, which
-    # serialises the streams, no longer agrees with them (profiles/r4z_streams_probe.txt).  The default stays at two streams.
-    more = None
-    if streams is not None and world == 1 and graphs is None and default_cfg and not args.no_side_legs:
+    # Reference points outside the timed region (same process, same inputs, same steps):
+    #  * other stream counts than the default, each with the in-region HIP-event time of the volume call under that schedule.
+    #    With three or more frames in flight the volume kernel's 256 workgroups (one whole CU each: all of its LDS) take their
+    #    CUs one by one as other frames' conv kernels drain, so an event bracket around the launch then holds the wait for CUs
+    #    as well -- it measures the schedule, not the kernel (profiles/r4z_streams_probe.txt), and a kernel trace, which
+    #    serialises the streams, reports the kernel's own duration at every stream count;
+    #  * the same steps strictly one after the other on one stream: the leg the dominant kernel's roofline figure is taken
+    #    from (its event bracket holds the kernel alone, as the kernel trace does).  Every rank runs it (the per-step exchange
+    #    is a collective), rank 0 reports.
+    def side_leg(n_streams, first_frame):
+        nonlocal streams
         n_main = len(events)
         keep = streams
-        streams = keep + [torch.cuda.Stream(device)]
-        streams[-1].wait_stream(torch.cuda.current_stream(device))
-        for i in range(2 * len(streams)):
-            step(args.warmup + args.steps + i)
+        if n_streams <= 1:
+            streams = None
+        else:
+            have = list(keep or [])
+            while len(have) < n_streams:
+                have.append(torch.cuda.Stream(device))
+                have[-1].wait_stream(torch.cuda.current_stream(device))
+            streams = have[:n_streams]
+        for i in range(2 * max(1, n_streams)):
+            step(first_frame + i)
         torch.cuda.synchronize(device)
-        cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
-        t2 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + args.steps + 2 * len(streams) + i, timed=True)
-        torch.cuda.synchronize(device)
-        el2 = time.perf_counter() - t2
-        cvmod.FeatureVolumeManager._event_hook = None
-        ev2 = events[n_main:]
-        del events[n_main:]
-        b2 = [e for tag, e, _ in ev2 if tag == "mlp_begin"]
-        e2 = [e for tag, e, _ in ev2 if tag == "mlp_end"]
-        more = {"streams": len(streams), "value": args.steps * CFG["batch"] / el2, "ms_per_step": el2 / args.steps * 1e3,
-                "dominant_kernel_avg_launch_ms_in_region": float(np.mean([b.elapsed_time(e) for b, e in zip(b2, e2)]))}
-        streams = keep
-
-    # reference point outside the driver's timed region: the same steps strictly one after the other on one stream
-    single = None
-    if streams is not None and world == 1:
-        n_main = len(events)
-        streams = None
-        torch.cuda.synchronize(device)
+        if use_dist:
+            dist.barrier()
         cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
         t1 = time.perf_counter()
         for i in range(args.steps):
-            step(args.warmup + args.steps + i, timed=True)
+            step(first_frame + 2 * max(1, n_streams) + i, timed=True)
         torch.cuda.synchronize(device)
-        el1 = time.perf_counter() - t1
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t1
         cvmod.FeatureVolumeManager._event_hook = None
-        ev1 = events[n_main:]
+        ev = events[n_main:]
         del events[n_main:]
-        b1 = [e for tag, e, _ in ev1 if tag == "mlp_begin"]
-        e1 = [e for tag, e, _ in ev1 if tag == "mlp_end"]
-        m1 = [e for tag, e, _ in ev1 if tag == "model_end"]
-        single = {"value": args.steps * CFG["batch"] / el1, "ms_per_step": el1 / args.steps * 1e3,
-                  "dominant_kernel_avg_launch_ms": float(np.mean([b.elapsed_time(e) for b, e in zip(b1, e1)]))}
-        if m1:
-            single["conv_stack_avg_ms"] = float(np.mean([b.elapsed_time(e) for b, e in zip(e1, m1)]))
+        streams = keep
+        bb = [e for tag, e, _ in ev if tag == "mlp_begin"]
+        ee = [e for tag, e, _ in ev if tag == "mlp_end"]
+        mm = [e for tag, e, _ in ev if tag == "model_end"]
+        leg = {"streams": max(1, n_streams), "value": args.steps * CFG["batch"] * world / el, "ms_per_step": el / args.steps * 1e3,
+               "dominant_kernel_avg_launch_ms": float(np.mean([x.elapsed_time(y) for x, y in zip(bb, ee)])) if bb else None}
+        if mm:
+            leg["conv_stack_avg_ms"] = float(np.mean([x.elapsed_time(y) for x, y in zip(ee, mm)]))
+        return leg
+
+    other_counts = []
+    if streams is not None and world == 1 and graphs is None and default_cfg and not args.no_side_legs:
+        for n_s in (2, 3, 4):
+            if n_s != args.streams:
+                other_counts.append(side_leg(n_s, args.warmup + args.steps + 40 * n_s))
+    single = None
+    if streams is not None:  # (--streams 1: the timed region itself is the strictly sequential run)
+        single = side_leg(1, args.warmup + 2 * args.steps + 200)
 
     # dominant kernel: average launch duration from the HIP events recorded on its stream
     begins = [e for tag, e, _ in events if tag == "mlp_begin"]
@@ -748,7 +850,15 @@ def main():
     if rank == 0:
         h, w = CFG["image_h"] // 4, CFG["image_w"] // 4
         flops = volume_flops(CFG["batch"], CFG["num_src"], h, w, CFG["planes"])
-        achieved = flops / (kern_ms * 1e-3) / 1e12
+        # The roofline figure of the dominant kernel comes from the leg in which the HIP events hold the kernel alone: the
+        # single-stream leg of this same run (same process, inputs and launches; every launch is bracketed).  With several
+        # frames in flight the in-region bracket also holds the kernel's wait for CUs that another frame's conv kernels still
+        # occupy; it is reported beside it.  (rocprofv3 --kernel-trace serialises the streams and reports the isolated figure
+        # at any stream count: profiles/*bench_kernel_stats*.csv.)
+        in_region_ms = kern_ms
+        iso_kern_ms = single["dominant_kernel_avg_launch_ms"] if single is not None else kern_ms
+        achieved = flops / (iso_kern_ms * 1e-3) / 1e12
+        kern_ms = iso_kern_ms
         frames = args.steps * CFG["batch"] * world
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the figure comes from
         # the last scripts/collect_pmc.sh pass -- and only while the kernel source it was measured on is the one built now
@@ -793,7 +903,11 @@ def main():
                 "input_sets": len(in_sets),  # distinct resident keyframes; step i processes set i % N
                 "launch": "hipGraph replay of the model step (4 segments, cut around the dominant kernel), one graph set per stream; "
                           "eager TSDF exchange/integrate" if graphs is not None else "eager",
-                "parallelism": f"keyframe-shard x{world}" + ("" if args.no_fuse else " + all_gather(depth,K,pose) + replica TSDF integrate"),
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "parallelism": f"keyframe-shard x{world}" + ("" if args.no_fuse else
+                               " + all_gather(depth,K,pose) + " + ("replica TSDF integrate" if args.tsdf_mode == "replica" else
+                               "x-slab TSDF integrate + one all_gather of the slabs at the end of the timed region")),
+                "tsdf": None if args.no_fuse else {"mode": args.tsdf_mode, "voxel_m": args.tsdf_res},
             },
             "roofline": {
                 "kernel": "cv_mlp_mfma_kernel (fused warp + metadata + matching MLP + hint MLP)" if args.mlp_precision == "fp32"
@@ -807,6 +921,14 @@ def main():
                 "traffic_profile": traffic_tag,
                 "algorithmic_flops_per_launch": flops,
                 "avg_launch_ms": kern_ms,
+                "measured_in": ("single-stream leg of this run: same process, inputs and launches, HIP events on the kernel's "
+                                "stream around each of the K launches, nothing else on the GPU") if single is not None else
+                               "the timed region (one stream: the events hold the kernel alone)",
+                # the same bracket inside the timed region, where --streams frames are in flight: it also holds the launch's
+                # wait for CUs still occupied by other frames' conv kernels (the kernel needs a whole CU per workgroup)
+                "in_region_avg_launch_ms": in_region_ms,
+                "in_region_frac": flops / (in_region_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if in_region_ms == in_region_ms else None,
+                "in_region_streams": args.streams,
                 # what the matrix pipe really executed (SQ_VALU_MFMA_BUSY_CYCLES / 64 x 4096 flop, same hash-checked PMC record
                 # as `traffic`): the kernel contracts the plane-invariant input columns once per pixel tile, so it executes
                 # fewer MFMAs than the algorithmic count.  mfma_busy_frac = executed flops / launch time / nominal peak = the
@@ -834,8 +956,8 @@ def main():
         if single is not None:
             single["frac_of_mfma_peak_isolated"] = flops / (single["dominant_kernel_avg_launch_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
             result["single_stream"] = single
-        if more is not None:
-            result["one_more_stream"] = more
+        if other_counts:
+            result["other_stream_counts"] = other_counts
         if use_dist:
             # self-verifying multi-GPU line: how many ranks RCCL really connected, and which RCCL
             result["config"]["ranks_seen"] = int(dist.get_world_size())
@@ -847,7 +969,7 @@ def main():
             result["roofline_warp_match_dot"] = dot_volume_roofline(device, t)
             if not args.no_side_legs:
                 result["roofline_tsdf"] = tsdf_roofline(device)
-                result["end_to_end"] = end_to_end(device, t, pyr_t, model)
+                result["end_to_end"], result["roofline_encoder"] = end_to_end(device, t, pyr_t, model, n_streams=args.streams)
         if not default_cfg:
             result["cpu_baseline"] = None  # the CPU leg is defined on the default workload
         if world == 1 and default_cfg and not args.no_cpu_baseline:
@@ -870,6 +992,8 @@ def main():
                 return [_finite(v) for v in o]
             return o
 
+        if default_cfg:
+            complete_line(result, world)
         print(json.dumps(_finite(result), allow_nan=False))
     if use_dist:
         dist.destroy_process_group()

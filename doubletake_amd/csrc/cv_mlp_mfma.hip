@@ -84,6 +84,10 @@ struct MlpArgs {
 
 // LeakyReLU(0.01) in two vector instructions: max(x, 0.01 x) == med3(x, 0.01 x, +inf) exactly; fmaxf() costs a third one
 // (it canonicalises x first).  pinf must be an OPAQUE +inf (see the kernel): a literal is folded back into fmaxf().
+// NaN: v_med3_f32 with a NaN operand falls back to min3, which returns the non-NaN operand -- a NaN activation leaves this
+// function as +inf, where the reference's leaky_relu (and the fmaxf form) returns NaN.  Finite inputs cannot produce a NaN
+// here (weights and features are finite, masked hints never enter as NaN: mesh_hint_volume.py:186-214), and a +inf still
+// poisons the pixel's score visibly; noted because it changes what a NaN diagnostic would show.
 __device__ __forceinline__ float lrelu01(float x, float pinf) { return __builtin_amdgcn_fmed3f(x, 0.01f * x, pinf); }
 
 // one source view's gathered taps + metadata, produced by issue_view(), consumed later
@@ -751,7 +755,8 @@ __global__ __launch_bounds__(256) void mlp_plan_bounds_kernel(const unsigned* __
   __syncthreads();
   const long nslots = (long)nblk * nwaves;
   const long j = (long)blockIdx.x * 256 + t;
-  if (j > nslots) return;
+  __shared__ int sout[256];
+  const bool have_slot = j <= nslots;
   // number of units whose cumulative price stays below `target` = the unit boundary behind the unit that reaches it
   auto bound_at = [&](long target) -> int {
     if (target <= 0) return 0;
@@ -773,8 +778,10 @@ __global__ __launch_bounds__(256) void mlp_plan_bounds_kernel(const unsigned* __
   auto price_upto = [&](int i) -> long { return i <= 0 ? 0L : gpre[(i - 1) >> 8] + (long)pref[i - 1]; };  // cumulative price of units [0, i)
   // cumulative price at which slot j begins: workgroup blk gets 1 / nblk of the total (remainder spread over the first ones),
   // inside it the older four waves old_share of that in equal parts, the younger four the rest
-  int out;
-  if (j == nslots) {
+  int out = 0;
+  if (!have_slot) {
+    // (threads beyond the end marker only take part in the barrier below)
+  } else if (j == nslots) {
     out = bound_at(total);
   } else {
     const long blk = j / nwaves;
@@ -802,6 +809,17 @@ __global__ __launch_bounds__(256) void mlp_plan_bounds_kernel(const unsigned* __
     } else {
       out = bound_at(b0 + (b1 - b0) * wv / nwaves);
     }
+  }
+  // The pair-compensated boundaries of waves 5..7 are rounded on their own and can fall before their predecessor's: the volume
+  // kernel's clamp keeps coverage complete either way, but two waves would then compute (and write, identically) the same
+  // units.  A running maximum over the slots of a workgroup (256 % nwaves == 0: they sit in one workgroup of this kernel)
+  // makes the spans disjoint.
+  sout[t] = out;
+  __syncthreads();
+  if (!have_slot) return;
+  if (j < nslots) {
+    const int wv = (int)(j % nwaves);
+    for (int q = 1; q <= wv; ++q) out = max(out, sout[t - q]);
   }
   bounds[j] = out;
 }

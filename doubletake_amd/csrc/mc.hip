@@ -381,6 +381,8 @@ static int fill(McArgs& a, const uint16_t* vol, const uint32_t* active, int X, i
   DT_REQUIRE(vol && active, "%s: null pointer", who);
   DT_REQUIRE(X > 1 && Y > 1 && Z > 1, "%s: bad volume extent", who);
   DT_REQUIRE(((size_t)X * Y * Z) % 256 == 0, "%s: voxel count must be a multiple of 256 (dims are multiples of 8)", who);
+  // every workgroup reads its eight bitmap words as two uint4 (early exit on an empty block)
+  DT_REQUIRE((reinterpret_cast<uintptr_t>(active) & 15) == 0, "%s: the active bitmap must be 16-byte aligned", who);
   a.vol = vol;
   a.active = active;
   a.X = X;

@@ -193,9 +193,14 @@ class _HotPathDepthModel(nn.Module):
                 pick = lambda j: cur_image[j // m] if j % m == 0 else src_image[j // m, j % m - 1]
                 imgs = pick(todo[0]).unsqueeze(0) if len(todo) == 1 else torch.stack([pick(j) for j in todo], 0)
                 new = self._encode(imgs)
+                from .. import _abi
+
+                # (ready token: a later keyframe processed on ANOTHER stream -- several keyframes in flight -- orders itself
+                #  behind this encoder pass when it takes the entry; free on the producing stream)
+                ready = _abi.record_ready(new.device)
                 for row, j in enumerate(todo):
                     have[flat_ids[j]] = new[row]
-                    cache.put(flat_ids[j], new[row])
+                    cache.put(flat_ids[j], new[row], ready)
             # the cached maps are gathered straight into the two tensors the volume takes (one stack for the source views,
             # none for the current view at batch 1) -- not stacked as one [b*(1+K)] tensor and sliced apart again
             got = [have[fid] for fid in flat_ids]
@@ -287,14 +292,24 @@ class _HotPathDepthModel(nn.Module):
                 if hook is not None:
                     hook(tag)
 
-        self._graphed_forward = GraphedCallable(self._forward_from_features_eager, between=between) if on else None
+        def cut_config():
+            # which cuts the eager function would place right now: part of the graph cache key, so that a graph captured
+            # before a hook was installed is not replayed (its hook never called) once one is
+            from ..modules.cost_volume import FeatureVolumeManager
+
+            return ("after_volume" in self.__dict__, FeatureVolumeManager._event_hook is not None)
+
+        self._graphed_forward = (GraphedCallable(self._forward_from_features_eager, between=between, cut_config=cut_config)
+                                 if on else None)
         self._graphed_encoder = GraphedCallable(lambda img: self.matching_model(img)) if on and self.matching_model is not None else None
         return self
 
     def _weights_token(self):
         # (data_ptr as well as the version counter: ``module.weight = nn.Parameter(...)`` or a swapped submodule brings a
         # new tensor at an old version, and the captured launches carry the old packed-weight pointers)
-        return tuple((p.data_ptr(), p._version, str(p.device)) for m in (self.cost_volume, self.cost_volume_net, self.depth_decoder)
+        # (no device string: a device move changes data_ptr.  The module trees are walked every call on purpose: a cached
+        # parameter list would miss ``module.weight = nn.Parameter(...)``)
+        return tuple((p.data_ptr(), p._version) for m in (self.cost_volume, self.cost_volume_net, self.depth_decoder)
                      for p in m.parameters())
 
     def _encode(self, images_n3hw):
@@ -302,7 +317,7 @@ class _HotPathDepthModel(nn.Module):
         exactly one new keyframe per frame)."""
         g = getattr(self, "_graphed_encoder", None)
         if g is not None and images_n3hw.shape[0] == 1:
-            token = tuple((p.data_ptr(), p._version, str(p.device)) for p in self.matching_model.parameters())
+            token = tuple((p.data_ptr(), p._version) for p in self.matching_model.parameters())
             if getattr(self, "_encoder_token", token) != token:
                 g.reset()
             self._encoder_token = token

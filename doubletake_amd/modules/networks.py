@@ -1,6 +1,6 @@
-"""MLP container with the reference's parameter names (modules/networks.py:120-135).
-
-The CVEncoder / DepthDecoderPP shims live in conv_networks.py and are re-exported here.
+"""The reference's modules/networks.py on the HIP conv primitive: ``MLP`` (parameter container with the reference's names,
+:120-135), ``CVEncoder`` (:88-117) and ``DepthDecoderPP`` (:20-85), all defined in this file; every forward is a sequence of
+launches through ``conv_ops`` (conv.hip).  ``ResnetMatchingEncoder`` (:138-189) lives in ``matching_encoder.py``.
 """
 from __future__ import annotations
 

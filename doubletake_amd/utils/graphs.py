@@ -67,11 +67,14 @@ def in_warmup():
 
 
 class GraphedCallable:
-    def __init__(self, fn, warmup=2, between=None):
-        """between(tag): called during replay after every graph segment that a ``cut(tag)`` call in fn ended."""
+    def __init__(self, fn, warmup=2, between=None, cut_config=None):
+        """between(tag): called during replay after every graph segment that a ``cut(tag)`` call in fn ended.
+        cut_config(): hashable describing which cuts fn WOULD make right now (e.g. which hooks are installed); it is part of
+        the cache key, so a graph captured without a cut is never replayed for a call that needs one (and vice versa)."""
         self.fn = fn
         self.warmup = max(2, int(warmup))
         self.between = between
+        self.cut_config = cut_config
         self._entries = {}
         self.captures = 0
         self.replays = 0
@@ -130,6 +133,8 @@ class GraphedCallable:
         sig = _flatten((args, kwargs), tensors)
         if not tensors or not tensors[0].is_cuda:
             raise RuntimeError("GraphedCallable needs ROCm GPU tensors (no CPU fallback)")
+        if self.cut_config is not None:
+            sig = (sig, self.cut_config())
         ent = self._entries.get(sig)
         if ent is None:
             ent = self._entries[sig] = self._capture(args, kwargs, tensors)
@@ -149,6 +154,8 @@ class GraphedCallable:
         first if needed.  A producer that writes straight into them saves the per-call copies."""
         tensors = []
         sig = _flatten((args, kwargs), tensors)
+        if self.cut_config is not None:
+            sig = (sig, self.cut_config())
         ent = self._entries.get(sig)
         if ent is None:
             ent = self._entries[sig] = self._capture(args, kwargs, tensors)

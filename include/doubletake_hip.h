@@ -392,6 +392,9 @@ int dt_tsdf_sample_f16(const uint16_t* volume, const float* origin3, float voxel
  * reads them once, allocates verts [V,3] f32 / faces [V/3,3] i64 / ids [V] i64 and calls
  * dt_mc_generate with the same arguments.  min_bounds3 / max_bounds3: HOST int[3] in (i,j,k)
  * order or NULL.  Output vertex coordinates use the reference's (x,y,z) = (k,j,i) order.
+ * Requirements checked by every entry point (error status otherwise): X*Y*Z is a multiple of 256
+ * (TSDF dims are multiples of VOX_MOD=8) and `active` -- 1 bit per voxel, voxel v = bit v%32 of
+ * word v/32 -- is 16-byte aligned (a workgroup reads its eight words as two 16-byte vectors).
  */
 int64_t dt_mc_workspace_bytes(int X, int Y, int Z);
 int dt_mc_count(const uint16_t* values_f16, const uint32_t* active, int X, int Y, int Z,

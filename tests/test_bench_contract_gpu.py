@@ -8,6 +8,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
 
 
 def test_bench_json_contract():
@@ -31,12 +33,33 @@ def test_bench_json_contract():
     assert rf["traffic"] is None or rf["traffic"] > 1e6
     dot = d["roofline_warp_match_dot"]
     assert dot["bound"] == "hbm" and dot["unit"] == "GB/s" and dot["peak"] == 8000.0
+    # the bound statement: the kernel is vector-issue bound, the HBM clause is answered by a number
+    bs = dot["bound_statement"]
+    assert dot["bound_by"] == "valu" and bs["hbm_time_floor_ms"] < 0.005 < bs["valu_issue_floor_ms"] < dot["avg_launch_ms"]
+    assert bs["max_hbm_frac_at_valu_floor"] < 0.40
     assert 0.0 < dot["valu_frac"] < 1.0 and 0.0 < dot["lds_frac"] < 1.0 and 0.0 < dot["batch8_512x384"]["lds_frac"] < 1.0
     rc = d["roofline_conv"]  # conv stack + heads next to the dominant kernel
     assert rc["bound"] == "mfma" and rc["peak"] == rf["peak"] and abs(rc["frac"] - rc["achieved"] / rc["peak"]) < 1e-9
     assert 7.0e10 < rc["direct_equivalent_flops_per_step"] < 8.5e10   # CVEncoder 37.0 G + SkipDecoder/heads 40.7 G
     assert 10 <= rc["launches"] <= 60 and rc["model_launches_per_step"] > rc["launches"]
     assert d["config"]["name"] == "cfg2_small"
+    # several keyframes in flight by default; the dominant kernel's figure comes from the isolated (single-stream) leg of
+    # the same run and says so, the in-region bracket stays beside it
+    import bench as _bench
+
+    assert d["config"]["streams"] == _bench.DEFAULT_STREAMS >= 3
+    assert "single-stream leg" in rf["measured_in"] and rf["in_region_streams"] == _bench.DEFAULT_STREAMS
+    assert abs(rf["avg_launch_ms"] - d["single_stream"]["dominant_kernel_avg_launch_ms"]) < 1e-9
+    assert rf["in_region_avg_launch_ms"] >= 0.9 * rf["avg_launch_ms"]
+    assert rf["avg_launch_ms"] <= d["ms_per_step"] * 1.05  # (a kernel of the step cannot last longer than the step)
+    assert {leg["streams"] for leg in d["other_stream_counts"]} == {2, 3, 4} - {_bench.DEFAULT_STREAMS}
+    assert all(k in d for k in _bench.LINE_KEYS)  # the same keys on every default-config line
+    assert d["cpu_baseline"] is None and d["parity"] is None and set(d["null_because"]) == {"cpu_baseline", "parity"}
+    enc = d["roofline_encoder"]
+    assert enc["bound"] == "mfma" and 0.05 < enc["frac"] < 1.0 and enc["batched_1_plus_K"]["images"] == 8
+    assert 6.0e10 < enc["batched_1_plus_K"]["direct_equivalent_flops"] < 7.0e10 and enc["single_image"]["launches"] >= 3
+    e2e = d["end_to_end"]
+    assert e2e["streams"] == 1 and e2e[f"streams_{_bench.DEFAULT_STREAMS}"]["cache_off"]["frames_per_s"] > 0
 
 
 def test_bench_other_baseline_shape_prints_the_same_contract():
@@ -66,12 +89,13 @@ def test_bench_graph_mode_keeps_the_roofline_bracket():
     d = json.loads(lines[0])
     assert d["config"]["launch"].startswith("hipGraph") and d["config"]["input_sets"] == 1
     assert 0.3 < d["roofline"]["frac"] < 1.0 and 0.3 < d["roofline"]["avg_launch_ms"] < 2.0
-    assert "one_more_stream" not in d  # (side legs skipped)
+    assert "other_stream_counts" not in d  # (side legs skipped)
 
 
-def test_two_stream_frame_pipelining_is_bit_identical():
-    """bench.py --streams 2 runs consecutive keyframes on alternating HIP streams with only the TSDF integrations
-    chained by events.  Same frames, same order: depth maps and the fused volume must not change by a bit."""
+def test_multi_stream_frame_pipelining_is_bit_identical():
+    """bench.py --streams S (default 4) runs consecutive keyframes round-robin on S HIP streams with only the TSDF
+    integrations chained by events.  Same frames, same order: depth maps and the fused volume must not change by a bit,
+    at 2, 3 and 4 keyframes in flight."""
     import numpy as np
     import torch
 
@@ -88,10 +112,10 @@ def test_two_stream_frame_pipelining_is_bit_identical():
     gu.set_formula_weights(model, 5)
     model = model.to(dev)
     bd = dict(xmin=-2.0, xmax=2.0, ymin=-2.0, ymax=2.0, zmin=0.0, zmax=2.4)
-    _, K, T = syn.tsdf_frames(6, 2 * h, 2 * w, seed=2, bounds=bd)
+    _, K, T = syn.tsdf_frames(9, 2 * h, 2 * w, seed=2, bounds=bd)
     Kt, Tt = torch.from_numpy(K).to(dev), torch.from_numpy(T).to(dev)
     frames = []
-    for f in range(6):
+    for f in range(9):
         t = gu.to_dev(syn.volume_inputs(1, k, h, w, 16, 30 + f))
         pyr = [torch.from_numpy(p).to(dev) for p in syn.prior_pyramid(1, [64, 64, 128, 256, 512], 2 * h, 2 * w, 40 + f)]
         frames.append((t, pyr))
@@ -118,8 +142,31 @@ def test_two_stream_frame_pipelining_is_bit_identical():
         return [o.clone() for o in outs], t.tsdf_values.clone(), t.tsdf_weights.clone()
 
     d1, v1, w1 = run(1)
-    d2, v2, w2 = run(2)
-    for a, b in zip(d1, d2):
-        assert torch.equal(a, b)
     assert (w1 > 0).sum().item() > 1000
-    assert torch.equal(v1.view(torch.int16), v2.view(torch.int16)) and torch.equal(w1.view(torch.int16), w2.view(torch.int16))
+    for nstreams in (2, 3, 4):
+        d2, v2, w2 = run(nstreams)
+        for a, b in zip(d1, d2):
+            assert torch.equal(a, b), nstreams
+        assert torch.equal(v1.view(torch.int16), v2.view(torch.int16)) and torch.equal(w1.view(torch.int16), w2.view(torch.int16)), nstreams
+
+
+def test_forced_collective_line_carries_every_key_of_the_plain_line():
+    """`bench.py --gpus 1 --force-dist` (the N > 1 code path on one GPU: RCCL group, per-step all_gather)
+    prints a line with every key of the plain N = 1 line, plus the evidence that RCCL connected the ranks; slab-mode TSDF
+    fusion runs through the same loop."""
+    import bench as _bench
+
+    base = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--force-dist"]
+    for extra in ([], ["--tsdf-mode", "slab", "--tsdf-res", "0.02", "--no-side-legs"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, cwd=REPO)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        assert all(k in d for k in _bench.LINE_KEYS)
+        assert d["config"]["ranks_seen"] == 1 and d["config"]["rccl_version"]
+        assert d["roofline"]["frac"] > 0.3 and d["roofline_conv"]["launches"] >= 10 and d["single_stream"]["value"] > 0
+        if extra:
+            assert d["config"]["tsdf"] == {"mode": "slab", "voxel_m": 0.02} and "x-slab" in d["config"]["parallelism"]
+        else:
+            assert d["config"]["tsdf"] == {"mode": "replica", "voxel_m": 0.04}

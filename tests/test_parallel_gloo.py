@@ -237,9 +237,21 @@ def test_slab_bounds_cover_the_volume():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and all(x0 <= x1 for x0, x1 in spans)
 
 
-# ---- bench.py's step order (two frames in flight on alternating streams) against the exchange ---------------------------
+# ---- bench.py's step order (several frames in flight, round-robin over the streams) against the exchange ---------------------------
+def _bench_default_streams():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_for_tests", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return int(mod.DEFAULT_STREAMS)
+
+
+BENCH_STREAMS = _bench_default_streams()  # keyframes in flight in bench.py's default run (round 5: 4)
+
+
 def _bench_order_worker(rank, world, port, out_dir):
-    """bench.py issues step i from HIP stream i % 2; the collective of a step is enqueued from whichever stream runs it.
+    """bench.py issues step i from HIP stream i % S (S = bench.DEFAULT_STREAMS); the collective of a step is enqueued from whichever stream runs it.
     What has to hold for RCCL is that every rank issues the SAME sequence of collectives (same order, same shapes) and
     integrates in the same canonical order -- the streams only change where the launch is enqueued.  Replayed here with the
     stream of a step recorded instead of used; the schedule ends ragged (7 keyframes on 2 ranks)."""
@@ -259,7 +271,7 @@ def _bench_order_worker(rank, world, port, out_dir):
     _, K, T = syn.tsdf_frames(8, h, w, seed=5, bounds=BD)
     issue = []
     for step in range((nframes + world - 1) // world):
-        stream = step % 2                       # bench.py: streams[frame_idx % len(streams)]
+        stream = step % BENCH_STREAMS           # bench.py: streams[frame_idx % len(streams)]
         g = step * world + rank                 # bench.py: (frame_idx * world + rank) -> camera / keyframe index
         counts = [1 if step * world + r < nframes else 0 for r in range(world)]
         have = g < nframes
@@ -277,9 +289,67 @@ def test_bench_step_order_issues_identical_collectives_on_every_rank(tmp_path):
     _spawn(_bench_order_worker, world, str(tmp_path))
     r0, r1 = (torch.load(os.path.join(tmp_path, f"bo{r}.pt")) for r in range(world))
     assert r0["calls"] == r1["calls"] and len(r0["calls"]) == 4          # one collective per step, same shapes, same order
-    assert r0["issue"] == r1["issue"] and [s for _, s, _ in r0["issue"]] == [0, 1, 0, 1]
+    assert r0["issue"] == r1["issue"] and [s for _, s, _ in r0["issue"]] == [i % BENCH_STREAMS for i in range(4)]
     assert r0["issue"][-1][2] == (1, 0)                                   # ragged last step: rank 1 has no keyframe
     assert r0["log"] == r1["log"] == [float(i + 1) for i in range(7)]     # canonical (= serial) integration order on both
+
+
+def _bench_line_worker(rank, world, port, out_dir):
+    """A bench.py-shaped step loop on two gloo ranks (the product kernels need a GPU; the loop, the exchange, the max-over-ranks
+    timing and the JSON assembly do not): rank 0 prints the line bench.py's `complete_line` would."""
+    import json
+    import time
+
+    _init(rank, world, port)
+    spec_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_for_tests", os.path.join(spec_dir, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    h, w, steps = 6, 8, 5
+    fused = []
+    fuser = par.KeyframeShardFuser(torch.device("cpu"), world, rank, (h, w), fuse_fn=lambda d, K, T: fused.append(int(d.shape[0])))
+    _, K, T = syn.tsdf_frames(steps * world, h, w, seed=5, bounds=BD)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for step in range(steps):
+        g = step * world + rank
+        fuser.exchange_and_fuse(torch.full((1, 1, h, w), float(g + 1)), torch.from_numpy(K[g:g + 1]), torch.from_numpy(T[g:g + 1]))
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    if rank == 0:
+        line = {"metric": "depth frames/sec (640x480, 7 src views, 64 planes)", "value": steps * world / elapsed, "unit": "frames/s",
+                "n_gpus": world, "steps": steps, "warmup": 0, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "step loop of bench.py on gloo", "ranks_seen": int(dist.get_world_size()),
+                           "frames_fused_per_step": fused[0]},
+                "roofline": {"bound": "mfma"}, "roofline_conv": {"bound": "mfma"}, "single_stream": {"value": 1.0}}
+        with open(os.path.join(out_dir, "line.json"), "w") as f:
+            f.write(json.dumps(bench.complete_line(line, world)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_bench_line_has_every_key_of_the_single_gpu_line(tmp_path):
+    """the line a 2-rank run prints carries every key of the N = 1 line (objects that are measured at N = 1
+    only are null with the reason), reports whole-job frames/s over the max-over-ranks time, and shows how many ranks met."""
+    import json
+
+    world = 2
+    _spawn(_bench_line_worker, world, str(tmp_path))
+    d = json.loads(open(os.path.join(tmp_path, "line.json")).read())
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_for_tests2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert all(k in d for k in bench.LINE_KEYS)
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["frames_fused_per_step"] == 2
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-9
+    assert d["cpu_baseline"] is None and "N=1 only" in d["null_because"]["cpu_baseline"]
+    assert d["roofline"] is not None and d["roofline_conv"] is not None and d["single_stream"] is not None
 
 
 # ---- revisit flow (test_revisit.py:104-260): first pass over a PREVIOUS scan, second pass over the new one -------------
