@@ -169,53 +169,72 @@ def cpu_baseline(inp, pyr, model, threads="8,all", batched=False):
         depths = {k.replace("log_", ""): torch.exp(v).numpy() for k, v in out.items() if k.startswith("log_depth")}
         return time.perf_counter() - t0, depths
 
-    # Bounded sample (about 25 s of CPU work instead of 95 s for full-frame repeats): ONE whole frame at 8 threads -- warm-up,
-    # the depth maps of the parity check, and a cross-check of the estimate -- then the volume loop over every
-    # SAMPLE_STRIDE-th plane (all planes run the same ops on the same shapes) 3 times at 8 threads (median) and once with
-    # every physical core, and the conv part (lowest cost, CVEncoder, decoder, exp) 3 times.  frame = stride x sample + rest.
+    # Bounded sample (about 30 s of CPU work): the quoted value is ONE WHOLE FRAME at 8 threads, timed after a first whole frame
+    # that serves as warm-up and supplies the depth maps of the parity check (no extrapolation in the quoted
+    # figure).  Cross-checks beside it: the volume loop over every SAMPLE_STRIDE-th plane (all planes run the same ops on the same
+    # shapes) x stride + the conv part, at 8 threads and once with every physical core; the batched (Fast-manager) volume once.
     SAMPLE_STRIDE = 4
     sample_ids = list(range(0, CFG["planes"], SAMPLE_STRIDE))
     scale = CFG["planes"] / float(len(sample_ids))
     prev = torch.get_num_threads()
     torch.set_num_threads(8)
+    v_cold, vol, planes = volume()
+    r_cold, depths = rest(vol, planes)
     v_full, vol, planes = volume()
-    r_full, depths = rest(vol, planes)
+    r_full, _ = rest(vol, planes)
+    frame8 = v_full + r_full
     rest_ts = sorted(rest(vol, planes)[0] for _ in range(3))
     rest_s = rest_ts[1]
     runs = {}
-    plan = [(8, 3)] + [(n, 1) for n in thread_counts if n != 8]
+    plan = [(8, 1)] + [(n, 1) for n in thread_counts if n != 8]
     for nt, n_timed in plan:
         torch.set_num_threads(nt)
         ts = sorted(volume(sample_ids)[0] for _ in range(n_timed))
         vs = ts[len(ts) // 2] * scale
         runs[nt] = dict(frame_s=vs + rest_s, volume_s=vs, timed_runs=n_timed)
-    best = min(runs, key=lambda n: runs[n]["frame_s"])
+    best_other = min((n for n in runs if n != 8), key=lambda n: runs[n]["frame_s"], default=None)
     batched_s = None
     if batched:
-        torch.set_num_threads(best)
+        torch.set_num_threads(8)
         t0 = time.perf_counter()
         tref.hint_volume_batched(*geo, hint=hint, hint_mlp=lin("cost_volume.hint_mlp"))
         batched_s = time.perf_counter() - t0
     torch.set_num_threads(prev)
-    per = "; ".join(f"{n} threads: frame {r['frame_s']:.2f} s (volume {r['volume_s']:.2f} s), "
-                    f"{'median of ' + str(r['timed_runs']) if r['timed_runs'] > 1 else 'one run'}" for n, r in runs.items())
+    # if every physical core beats 8 threads by the extrapolated estimate, quote that (never happened: the per-plane ops are
+    # small and all-core runs lose to synchronisation) -- scaled by the measured-frame / extrapolated-frame ratio at 8 threads
+    value_frame_s, cores = frame8, 8
+    if best_other is not None and runs[best_other]["frame_s"] < runs[8]["frame_s"]:
+        value_frame_s, cores = runs[best_other]["frame_s"] * frame8 / runs[8]["frame_s"], best_other
+    per = "; ".join(f"{n} threads: frame {r['frame_s']:.2f} s (volume {r['volume_s']:.2f} s)" for n, r in runs.items())
+    port_ratio = None
+    try:  # measured in the build container, where the reference can be imported (scripts/cpu_ref_vs_port.py)
+        rv = json.load(open(os.path.join(REPO, "profiles", "r5_cpu_ref_vs_port.json")))
+        port_ratio = {"port_over_reference_frame_time": rv["port_over_reference"]["frame_s"], "threads": rv["threads"],
+                      "cpu_model": rv["cpu_model"], "reference_frame_s": rv["reference"]["frame_s"], "port_frame_s": rv["port"]["frame_s"],
+                      "max_abs_output_diff": max(rv["max_abs_diff"].values()), "source": "profiles/r5_cpu_ref_vs_port.json"}
+    except Exception:
+        pass
     res = {
-        "value": 1.0 / runs[best]["frame_s"],
+        "value": 1.0 / value_frame_s,
         "unit": "frames/s",
-        "cores": best,
+        "cores": cores,
         "kind": "port",
         "cpu_model": cpu_model,
         "physical_cores": phys,
-        "frames_per_s_by_threads": {str(n): 1.0 / r["frame_s"] for n, r in runs.items()},
+        "whole_frame_s": {"threads": 8, "second_run": frame8, "first_run_cold": v_cold + r_cold, "volume_s": v_full, "convs_s": r_full},
+        "frames_per_s_by_threads_extrapolated": {str(n): 1.0 / r["frame_s"] for n, r in runs.items()},
         "volume_batched_s": batched_s,
-        "sample": f"the same frame the GPU steps process (mesh-hint volume looped over the planes + lowest cost + CVEncoder + "
-                  f"SkipDecoderRegression + exp) through the torch-CPU restatement oracle/torch_cpu_ref.py, fp32, on {cpu_model}; "
-                  f"bounded sample: volume loop over every {SAMPLE_STRIDE}th of the {CFG['planes']} planes (x{scale:g}) + the conv part "
-                  f"({rest_s:.2f} s, median of 3): {per}; cross-check: the one whole frame run first at 8 threads (cold) took "
-                  f"{v_full + r_full:.2f} s (volume {v_full:.2f} s); " + (f"batched (Fast-manager) volume alone at {best} threads: "
-                                                                          f"{batched_s:.2f} s; " if batched_s is not None else "")
-                  + "value = best setting.  Sanity anchor: the reference itself measured 4.93 s (volume) + 0.12 s (convs) per "
-                    "frame on 8 vCPUs (BASELINE.md 2)",
+        "port_vs_reference": port_ratio,
+        "sample": f"ONE WHOLE FRAME -- the same frame the GPU steps process (mesh-hint volume looped over the {CFG['planes']} planes + "
+                  f"lowest cost + CVEncoder + SkipDecoderRegression + exp) through the torch-CPU restatement oracle/torch_cpu_ref.py, "
+                  f"fp32, 8 threads, on {cpu_model}: {frame8:.2f} s (volume {v_full:.2f} s; the run before it, cold, {v_cold + r_cold:.2f} s).  "
+                  f"Cross-check by extrapolation (volume loop over every {SAMPLE_STRIDE}th plane x{scale:g} + conv part {rest_s:.2f} s): {per}; "
+                  + (f"batched (Fast-manager) volume alone at 8 threads: {batched_s:.2f} s; " if batched_s is not None else "")
+                  + ("the restatement against the reference ITSELF on the same cores, threads and frame (build container, "
+                     f"{port_ratio['cpu_model']}, {port_ratio['threads']} threads): port {port_ratio['port_frame_s']:.2f} s vs reference "
+                     f"{port_ratio['reference_frame_s']:.2f} s per frame = x{port_ratio['port_over_reference_frame_time']:.3f}, outputs "
+                     f"identical (max abs diff {port_ratio['max_abs_output_diff']:g})" if port_ratio else
+                     "port-vs-reference ratio: profiles/r5_cpu_ref_vs_port.json not found"),
     }
     return res, depths
 

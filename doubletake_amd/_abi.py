@@ -52,6 +52,7 @@ SIGNATURES = {
     "dt_cv_mlp_pack_floats": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "dt_cv_mlp_hint_f32": (_I, [_P] * 11 + [_I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dt_cv_mlp_plan_bytes": (_L, [_I, _I, _I, _I]),
+    "dt_cv_mlp_set_cu_budget": (_I, [_I]),
     "dt_cv_mlp_plan_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "dt_cv_mlp_hint_planned_f32": (_I, [_P] * 11 + [_I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "dt_cv_mlp_split_pack_halves": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

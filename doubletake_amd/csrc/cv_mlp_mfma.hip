@@ -25,6 +25,7 @@
 // weights and the tail (b2, W3, b3) resident in LDS (152.6 KB for K=7).
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -888,7 +889,12 @@ static const int* mlp_tile_order(int h, int w, hipStream_t st) {
 
 // waves per workgroup of the fused kernel (4 = one per SIMD, 8 = two per SIMD); DT_MLP_WAVES overrides
 static int g_mlp_waves = [] { const char* e = getenv("DT_MLP_WAVES"); return (e && e[0] == '4') ? 4 : 8; }();
-static int num_cus() { return device_cu_count(); }
+// compute-unit budget of the volume kernel (dt_cv_mlp_set_cu_budget; 0 = the whole device); DT_MLP_CUS presets it
+static std::atomic<int> g_mlp_cu_budget{[] { const char* e = getenv("DT_MLP_CUS"); return e ? atoi(e) : 0; }()};
+static int num_cus() {
+  const int dev = device_cu_count(), b = g_mlp_cu_budget.load(std::memory_order_relaxed);
+  return (b > 0 && b < dev) ? std::max(8, b / 8 * 8) : dev;
+}
 
 }  // namespace dt
 
@@ -991,6 +997,11 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
                        int num_planes, dt_stream_t s) {
   return mlp_hint_launch(cur, src, params, w1dyn, w1pix, w2p, tail, hint_mlp, depth_hint, hint_weights, hint_mask, hint_h,
                          hint_w, volume, out_nhwc, batch, num_src, h, w, num_planes, nullptr, s);
+}
+
+int dt_cv_mlp_set_cu_budget(int cus) {
+  g_mlp_cu_budget.store(cus > 0 ? cus : 0, std::memory_order_relaxed);
+  return num_cus();
 }
 
 int64_t dt_cv_mlp_plan_bytes(int batch, int h, int w, int num_planes) {

@@ -129,6 +129,15 @@ int dt_cv_mlp_hint_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc
  * arguments earlier on the same stream (or ordered before it); where the plan does not apply (more source views than the kernel
  * keeps in LDS, DT_MLP_PLAN=0) dt_cv_mlp_plan_f32 launches nothing and the planned call uses equal-length spans. */
 int64_t dt_cv_mlp_plan_bytes(int batch, int h, int w, int num_planes);
+/* Compute-unit budget of the fused volume kernel (round 5: spatial partition of the chip).  The kernel is persistent -- one
+ * workgroup per compute unit, each owning the whole unit (all of its LDS and registers) -- so with several keyframes in flight
+ * it alternates with the latency-bound conv stacks of the other frames instead of running beside them.  With a budget of
+ * `cus` (> 0, rounded down to a multiple of 8, at most the device's count; 0 = the whole device, the default) every later
+ * dt_cv_mlp_plan_f32 / dt_cv_mlp_hint*_f32 call launches only that many workgroups, leaving the other compute units to kernels of
+ * other streams for the whole launch.  Same volume (the budget only changes how the (tile, plane) units are dealt to waves).
+ * Process-wide; set it before a plan is written, and do not change it between dt_cv_mlp_plan_f32 and the planned call that
+ * consumes the plan.  Returns the budget now in force. */
+int dt_cv_mlp_set_cu_budget(int cus);
 int dt_cv_mlp_plan_f32(const float* params, int batch, int num_src, int h, int w, int num_planes, void* plan_scratch,
                        int64_t plan_scratch_bytes, dt_stream_t s);
 int dt_cv_mlp_hint_planned_f32(const float* cur_feats_bchw, const float* src_feats_bkhwc,

@@ -38,6 +38,11 @@ class FixedPyramid(nn.Module):
 
 def main():
     dev = torch.device("cuda:0")
+    # DT_CONFIG=cfg4_small: the shape BASELINE.json configs[3] names for the incremental mode (512x384); default: the headline
+    # frame size (640x480), where the model step alone is 1.69 ms on one stream
+    cfg_name = os.environ.get("DT_CONFIG", "cfg2_small")
+    bench.CFG.clear()
+    bench.CFG.update(bench.CONFIGS[cfg_name])
     inp, pyr, t, pyr_t = bench.build_inputs(dev, 1000)
     model = bench.build_model(dev)
     model.encoder = FixedPyramid(pyr_t)
@@ -78,7 +83,7 @@ def main():
         out["depth_pred_s0_b1hw"] = out["depth_pred_s0_b1hw"].clamp(1.0, 2.5)
         return out
 
-    res = {}
+    res = {"config": cfg_name, "image": [H, W]}
     modes = os.environ.get("DT_MODES", "serial,lookahead,graphs,graphs+lookahead,serial,graphs+lookahead").split(",")
     for mode in modes:
         model.matching_feature_cache.clear()

@@ -89,7 +89,7 @@ def test_bench_graph_mode_keeps_the_roofline_bracket():
     d = json.loads(lines[0])
     assert d["config"]["launch"].startswith("hipGraph") and d["config"]["input_sets"] == 1
     assert 0.3 < d["roofline"]["frac"] < 1.0 and 0.3 < d["roofline"]["avg_launch_ms"] < 2.0
-    assert "other_stream_counts" not in d  # (side legs skipped)
+    assert d["other_stream_counts"] is None and "other_stream_counts" in d["null_because"]  # (side legs skipped)
 
 
 def test_multi_stream_frame_pipelining_is_bit_identical():
