@@ -435,7 +435,7 @@ def encoder_flops_per_image(H, W, c_out=16):
     return 2.0 * (147 * 64 * p2 + 4 * 576 * 64 * p4 + 64 * 128 * p4 + 1152 * c_out * p4)
 
 
-def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1):
+def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1, set_plan=None):
     """Frames/s of the reference entry point ``model("test", cur_data, src_data)`` INCLUDING the HIP matching encoder
     (ResnetMatchingEncoder, reference modules/networks.py:138-189) on the 1 + K images of every keyframe -- the step just
     before the volume that the headline (forward_from_features) leaves outside.  Image-prior encoder: out of scope (a
@@ -483,6 +483,8 @@ def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1):
     try:
         for ns, streams in ((1, None),) + (((n_streams, side),) if side else ()):
             leg = {}
+            if set_plan is not None:
+                leg["conv_plan_mask"] = set_plan(ns)  # (latency plan on one stream, throughput plan with keyframes in flight)
             for mode, cache in (("cache_off", False), ("cache_on", True)):
                 model.matching_feature_cache.clear()
                 model.use_feature_cache = cache
@@ -513,6 +515,8 @@ def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1):
             else:
                 res[f"streams_{ns}"] = leg
         # the matching encoder alone: 1 + K images in one pass (cache off) and one image (cache on / incremental mode)
+        if set_plan is not None:
+            set_plan(1)
         L = _abi.lib()
         enc = {"kernels": "stem_conv (7x7/2 + bn + relu) + maxblur + 4 x conv_wino (layer1) + conv 1x1 + instnorm (+LeakyReLU) + "
                           "conv 3x3 replicate + instnorm (ResnetMatchingEncoder, reference modules/networks.py:138-189)",
@@ -531,6 +535,8 @@ def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1):
         model.use_feature_cache = prev_cache
         model.encoder = prev_enc
         model.matching_feature_cache.clear()
+        if set_plan is not None:
+            set_plan(n_streams)
     return res, enc
 
 
@@ -583,6 +589,10 @@ def main():
                     help="run consecutive keyframes on this many HIP streams (frames are independent in this workload; the "
                          "TSDF integrations stay in frame order).  The dominant kernel's roofline figure comes from the "
                          "single-stream leg of the same run (with several frames in flight an event bracket measures the schedule)")
+    ap.add_argument("--conv-plan", default="auto",
+                    help="plan objective of the conv launchers: 'latency' (one keyframe at a time), 'throughput' (several keyframes "
+                         "in flight: conv_ops.PLAN_THROUGHPUT), an integer bit mask (include/doubletake_hip.h), or 'auto' (default): "
+                         "throughput while more than one keyframe is in flight, latency in the single-stream leg")
     ap.add_argument("--tsdf-mode", choices=("replica", "slab"), default="replica",
                     help="TSDF fusion of the gathered frames: every rank integrates all of them into a whole replica volume "
                          "(default), or only into its x-slab of the volume, completed by one all_gather of the slabs at the end "
@@ -649,6 +659,17 @@ def main():
     from doubletake_amd.modules import conv_ops as _conv_ops
 
     _conv_ops.CONV_PRECISION = args.conv_precision
+
+    def conv_plan_for(n_streams):
+        """objective mask for a leg with n_streams keyframes in flight"""
+        if args.conv_plan == "auto":
+            return _conv_ops.PLAN_THROUGHPUT if n_streams > 1 else _conv_ops.PLAN_LATENCY
+        if args.conv_plan in ("latency", "throughput"):
+            return _conv_ops.PLAN_THROUGHPUT if args.conv_plan == "throughput" else _conv_ops.PLAN_LATENCY
+        return int(args.conv_plan)
+
+    if "DT_CONV_OBJ" not in os.environ:  # (an explicit environment preset wins: experiment hook)
+        _conv_ops.set_plan_objective(conv_plan_for(args.streams))
     hint = {n: t[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
     # the keyframes the steps rotate through: set 0 above plus N-1 more with their own seeds (about 9 MB each at cfg2)
     in_sets = [(t, pyr_t, hint)]
@@ -797,6 +818,8 @@ def main():
         nonlocal streams
         n_main = len(events)
         keep = streams
+        if "DT_CONV_OBJ" not in os.environ:
+            _conv_ops.set_plan_objective(conv_plan_for(n_streams))
         if n_streams <= 1:
             streams = None
         else:
@@ -822,10 +845,13 @@ def main():
         ev = events[n_main:]
         del events[n_main:]
         streams = keep
+        leg_plan = int(os.environ["DT_CONV_OBJ"]) if "DT_CONV_OBJ" in os.environ else conv_plan_for(n_streams)
+        if "DT_CONV_OBJ" not in os.environ:
+            _conv_ops.set_plan_objective(conv_plan_for(args.streams))
         bb = [e for tag, e, _ in ev if tag == "mlp_begin"]
         ee = [e for tag, e, _ in ev if tag == "mlp_end"]
         mm = [e for tag, e, _ in ev if tag == "model_end"]
-        leg = {"streams": max(1, n_streams), "value": args.steps * CFG["batch"] * world / el, "ms_per_step": el / args.steps * 1e3,
+        leg = {"streams": max(1, n_streams), "conv_plan_mask": leg_plan, "value": args.steps * CFG["batch"] * world / el, "ms_per_step": el / args.steps * 1e3,
                "dominant_kernel_avg_launch_ms": float(np.mean([x.elapsed_time(y) for x, y in zip(bb, ee)])) if bb else None}
         if mm:
             leg["conv_stack_avg_ms"] = float(np.mean([x.elapsed_time(y) for x, y in zip(ee, mm)]))
@@ -923,6 +949,9 @@ def main():
                 "launch": "hipGraph replay of the model step (4 segments, cut around the dominant kernel), one graph set per stream; "
                           "eager TSDF exchange/integrate" if graphs is not None else "eager",
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                # plan objective of the conv launchers in the timed region (0 = latency, 3 = throughput: doubletake_hip.h); the
+                # single-stream leg runs the latency plan under --conv-plan auto (its own conv_plan_mask says which)
+                "conv_plan_mask": int(os.environ["DT_CONV_OBJ"]) if "DT_CONV_OBJ" in os.environ else conv_plan_for(args.streams),
                 "parallelism": f"keyframe-shard x{world}" + ("" if args.no_fuse else
                                " + all_gather(depth,K,pose) + " + ("replica TSDF integrate" if args.tsdf_mode == "replica" else
                                "x-slab TSDF integrate + one all_gather of the slabs at the end of the timed region")),
@@ -988,7 +1017,9 @@ def main():
             result["roofline_warp_match_dot"] = dot_volume_roofline(device, t)
             if not args.no_side_legs:
                 result["roofline_tsdf"] = tsdf_roofline(device)
-                result["end_to_end"], result["roofline_encoder"] = end_to_end(device, t, pyr_t, model, n_streams=args.streams)
+                result["end_to_end"], result["roofline_encoder"] = end_to_end(
+                    device, t, pyr_t, model, n_streams=args.streams,
+                    set_plan=None if "DT_CONV_OBJ" in os.environ else (lambda ns: _conv_ops.set_plan_objective(conv_plan_for(ns))))
         if not default_cfg:
             result["cpu_baseline"] = None  # the CPU leg is defined on the default workload
         if world == 1 and default_cfg and not args.no_cpu_baseline:

@@ -65,6 +65,7 @@ SIGNATURES = {
     "dt_conv_pack_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "dt_conv2d_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "dt_conv_transposed_tiling": (_I, [C.POINTER(ConvDesc)]),
+    "dt_conv_set_plan_objective": (_I, [_I]),
     "dt_conv_wino_pack_floats": (_L, [_I, _I]),
     "dt_conv_wino_pack_f32": (_I, [_P, _P, _I, _I, _P]),
     "dt_conv2d_wino_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),

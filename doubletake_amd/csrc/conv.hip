@@ -17,6 +17,7 @@
 // 1024 SIMDs.  Bias, residual add, LeakyReLU/ELU, channel concat of up to three sources and
 // nearest x2 upsampling of a source are fused (never materialised).
 #include <array>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -1307,6 +1308,21 @@ static int fill_args(const dt_conv_desc* d, const float* in0, const float* in1, 
 // ---- cross-workgroup K split: policy and workspace ---------------------------------------------------------------------
 static int device_cus() { return device_cu_count(); }
 
+// Plan objective (dt_conv_set_plan_objective, round 5).  The launch plans below were tuned for the LATENCY of one launch on an
+// otherwise idle chip: K split over 8 waves or over several workgroups so that a small layer still covers the CUs.  Those
+// choices buy latency with resources -- a 512-thread K-split workgroup at 144 registers owns its CU (no second one fits), a
+// cross-workgroup split adds partial-tile traffic and an atomic round trip -- which is the wrong trade when several
+// independent frames are in flight and another stream's kernels could use what is left over (bench.py, 4 keyframes in flight:
+// profiles/r5b_conv_env_probe.txt).  Bits of the objective mask:
+//   1  Winograd layers never split K inside the workgroup (256-thread workgroups, three per CU)
+//   2  direct 3x3 K-split kernels use 4 waves instead of 8
+//   4  no K split across workgroups
+//   8  no tail split (whole blocks first, leftovers in parts)
+//   16 low-resolution 1x1 convolutions on the plain kernel (no in-workgroup K split)
+// 0 = latency (default).  DT_CONV_OBJ presets it.
+static std::atomic<int> g_conv_obj{[] { const char* e = getenv("DT_CONV_OBJ"); return e ? atoi(e) : 0; }()};
+static inline int conv_obj() { return g_conv_obj.load(std::memory_order_relaxed); }
+
 // Number of workgroups P that share one output block of a K-split kernel.  Measured on the K-split kernels
 // (scripts/conv_quantisation.py, profiles/r2p_conv_quantisation.txt): a launch lasts about
 //     4 us + max over CUs of the sum over the CU's workgroups of (4.1 us + K steps per wave x waves per SIMD x step time),
@@ -1346,6 +1362,7 @@ static double launch_cost_us(const KSeg* seg, const int* P, int nseg, int cus) {
 static void plan_kparts(const KSeg* seg, int nseg, int* P) {
   static const int forced = [] { const char* e = getenv("DT_CONV_KPARTS"); return e ? atoi(e) : 0; }();
   for (int i = 0; i < nseg; ++i) P[i] = 1;
+  if (conv_obj() & 4) return;
   if (forced == 1 || forced == 2 || forced == 4) {
     for (int i = 0; i < nseg; ++i)
       if (seg[i].can_split && seg[i].groups >= seg[i].split * forced) P[i] = forced;
@@ -1500,6 +1517,7 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
   else if (blocks * 4 < 2048 && a.groups >= 16) split = 8;
   static const int force_split = [] { const char* e = getenv("DT_CONV_SPLIT"); return e ? atoi(e) : 0; }();
   if (split != 1 && (force_split == 4 || force_split == 8)) split = force_split;
+  if (split == 8 && (conv_obj() & 2)) split = 4;
   long grid = blocks;
   if (d->ksize == 3 && split != 1) {
     const KSeg seg = {blocks, a.groups, split, 3, true};
@@ -1508,7 +1526,7 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
     // split, into about one small workgroup per CU -- a second round of 1/P-sized instead of full-sized workgroups
     static const int tail_mode = [] { const char* e = getenv("DT_CONV_TAIL_SPLIT"); return e ? atoi(e) : 1; }();
     const int cus = device_cus();
-    if (tail_mode && a.kparts == 1 && blocks > cus && blocks < 2L * cus && cus % 8 == 0) {
+    if (tail_mode && !(conv_obj() & (4 | 8)) && a.kparts == 1 && blocks > cus && blocks < 2L * cus && cus % 8 == 0) {
       const long rest = blocks - cus;
       const int P = (rest * 4 <= cus + cus / 4) ? 4 : 2;  // rest x P ~ one workgroup per CU
       if (a.groups >= split * P) {
@@ -1539,9 +1557,10 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
     const long waves = pix_blocks * a.co_blocks;
     // few pixels, long K (the low-resolution downsample convs): one wave per block leaves most SIMDs idle
     // and runs hundreds of dependent MFMAs in a row -> K-split variant of the tiled kernel instead
-    if (waves < 1024 && a.groups >= 32 && blocks * 8 < 2048)
+    const bool plain_1x1 = (conv_obj() & 16) && !a.tr;
+    if (!plain_1x1 && waves < 1024 && a.groups >= 32 && blocks * 8 < 2048)
       launch_split16<1, 1>(a, blocks, st);
-    else if (waves < 1024 && a.groups >= 16)
+    else if (!plain_1x1 && waves < 1024 && a.groups >= 16)
       DT_LAUNCH((conv_mfma_kernel<1, 1, 8>), dim3((unsigned)blocks), dim3(512), 0, st, a);
     else {
       DT_REQUIRE(!a.tr, "dt_conv2d_f32: transposed tiling needs a K-split kernel (see dt_conv_transposed_tiling)");
@@ -1595,13 +1614,13 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
   DT_REQUIRE(blocks < 2147483647L, "dt_conv2d_wino_f32: grid too large");
   // few output blocks (the 60x80 level and below): split K over two groups of four waves
   static const int force_split = [] { const char* e = getenv("DT_WINO_KSPLIT"); return e ? atoi(e) : 0; }();
-  const int ksplit = force_split ? force_split : ((blocks < 256 && a.groups >= 8) ? 2 : 1);
+  const int ksplit = force_split ? force_split : ((blocks < 256 && a.groups >= 8 && !(conv_obj() & 1)) ? 2 : 1);
   // cross-workgroup K split (see plan_kparts): all parts when the P-fold workgroup count still fits one round of CUs,
   // only the leftover blocks when the launch is slightly larger than the chip (300 blocks at 120x160)
   static const int wino_parts = [] { const char* e = getenv("DT_WINO_KPARTS"); return e ? atoi(e) : -1; }();
   const int cus = device_cus();
-  if (wino_parts != 0 && ksplit <= 2) {
-    if (blocks > cus && blocks < 2L * cus && cus % 8 == 0) {
+  if (wino_parts != 0 && ksplit <= 2 && !(conv_obj() & 4)) {
+    if (blocks > cus && blocks < 2L * cus && cus % 8 == 0 && !(conv_obj() & 8)) {
       const long rest = blocks - cus;
       const int P = (rest * 4 <= cus + cus / 4) ? 4 : 2;
       if (a.groups >= ksplit * P * 2) {
@@ -1636,11 +1655,12 @@ static ConvPick pick_direct(const ConvArgs& a, const dt_conv_desc* d) {
   if (d->ksize == 3) {
     const long k_steps = (long)a.groups * 9;
     if (blocks >= 4096 || k_steps <= 16) return PICK_WSHARE;
-    if (blocks * 4 < 2048 && a.groups >= 16) return PICK_SPLIT8;
+    if (blocks * 4 < 2048 && a.groups >= 16 && !(conv_obj() & 2)) return PICK_SPLIT8;
     return PICK_SPLIT4;
   }
   const long pix_blocks = ((long)a.n * a.h_out * a.w_out + 31) / 32;
   const long waves = pix_blocks * a.co_blocks;
+  if ((conv_obj() & 16) && !a.tr) return PICK_1X1_PLAIN;
   if (waves < 1024 && a.groups >= 32 && blocks * 8 < 2048) return PICK_1X1_SPLIT16;
   if (waves < 1024 && a.groups >= 16) return PICK_1X1_SPLIT8;
   return PICK_1X1_PLAIN;
@@ -1694,7 +1714,7 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
   if (a_wino) {
     const long wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
     const long blocks_a = (long)a.n * wt_y * wt_x * a.co_blocks;
-    const int ksplit = (blocks_a < 256 && a.groups >= 8) ? 2 : 1;
+    const int ksplit = (blocks_a < 256 && a.groups >= 8 && !(conv_obj() & 1)) ? 2 : 1;
     if (ksplit == 1 && pb == PICK_1X1_PLAIN) {
       const long pix_blocks = ((long)b.n * b.h_out * b.w_out + 31) / 32;
       DT_PAIR(WinoBody<1>, OneByOneBody, blocks_a, (pix_blocks * b.co_blocks + 3) / 4);
@@ -1704,7 +1724,7 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
       // workgroups fill in behind them
       static const int wino_parts = [] { const char* e = getenv("DT_WINO_KPARTS"); return e ? atoi(e) : -1; }();
       const int cus = device_cus();
-      if (wino_parts != 0 && blocks_a < cus)
+      if (wino_parts != 0 && blocks_a < cus && !(conv_obj() & 4))
         for (int P = 4; P >= 2; P /= 2)
           if ((wino_parts < 0 || P <= wino_parts) && blocks_a * P <= cus && a.groups >= ksplit * P * 2) {
             a.kparts = P;
@@ -1728,6 +1748,11 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
                   : dt_conv2d_f32(da, in0, in1, in2, packed_wa, bias_a, nullptr, out_a, s);
   if (rc) return rc;
   return dt_conv2d_f32(db, in0, in1, in2, packed_wb, bias_b, nullptr, out_b, s);
+}
+
+int dt_conv_set_plan_objective(int mask) {
+  g_conv_obj.store(mask < 0 ? 0 : mask, std::memory_order_relaxed);
+  return conv_obj();
 }
 
 int dt_conv2d_simple_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* W,

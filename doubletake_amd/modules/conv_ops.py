@@ -155,6 +155,29 @@ SPLIT_MIN_BLOCKS = int(_os.environ.get("DT_CONV_SPLIT_MIN_BLOCKS", "128"))
 WINO_MIN_BLOCKS = int(_os.environ.get("DT_CONV_WINO_MIN_BLOCKS", "96"))
 
 
+#: Plan objective of the conv launchers (include/doubletake_hip.h: dt_conv_set_plan_objective).  PLAN_LATENCY: every launch as
+#: short as possible on an otherwise idle chip (one keyframe at a time: the incremental mode).  PLAN_THROUGHPUT: several
+#: independent keyframes in flight on HIP streams -- no in-workgroup K split of the Winograd layers, 4 instead of 8 waves in the
+#: direct K-split kernels, no tail split (bits 1 + 2 + 8), and the Winograd kernel down to the 15x20 level (fewer MFMAs; slower
+#: as a lone launch) -- so that another frame's workgroups fit beside them.  bench.py with 4 keyframes in flight: 745 -> 774-779
+#: frames/s, single stream 1.69 -> 1.80-1.85 ms (profiles/r5b_conv_env_probe.txt, r5c_conv_obj_probe.txt: every bit and
+#: combination measured; switching the cross-workgroup K split off as well, bit 4, loses what the others gain).  Same products
+#: either way (the fp32 summation order of a K split can differ); process-wide.
+PLAN_LATENCY = 0
+PLAN_THROUGHPUT = 11
+_WINO_MIN_BLOCKS_BY_PLAN = {False: 96, True: 48}  # (throughput plan: True)
+
+
+def set_plan_objective(mask):
+    """Select the plan objective (PLAN_LATENCY / PLAN_THROUGHPUT or a bit mask, see the header); returns the mask in force.
+    Also moves the Winograd threshold (WINO_MIN_BLOCKS) unless DT_CONV_WINO_MIN_BLOCKS pins it."""
+    global WINO_MIN_BLOCKS
+    got = int(_abi.lib().dt_conv_set_plan_objective(int(mask)))
+    if "DT_CONV_WINO_MIN_BLOCKS" not in _os.environ:
+        WINO_MIN_BLOCKS = _WINO_MIN_BLOCKS_BY_PLAN[bool(got & 1)]
+    return got
+
+
 def _dev_param(conv, name, device):
     """fp32 device copy of a small parameter (bias / head weight), cached per version."""
     p = getattr(conv, name)

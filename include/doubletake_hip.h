@@ -240,6 +240,16 @@ int dt_conv2d_f32(const dt_conv_desc* d, const float* in0, const float* in1, con
  * transposed tiling (d->transposed is ignored on input); the caller then sets d->transposed = 1 and passes weights packed
  * from W.transpose(2,3). */
 int dt_conv_transposed_tiling(const dt_conv_desc* d);
+/* Plan objective of the conv launchers (round 5).  0 (default) = latency: a layer that cannot fill the chip splits its K loop over
+ * 8 waves and / or several workgroups so that ONE launch on an idle chip finishes as early as possible.  With several
+ * independent frames in flight (streams) that buys latency with resources another stream's kernels could use: a bit mask
+ * switches the individual choices off -- 1: Winograd layers keep 256-thread workgroups (no in-workgroup K split); 2: direct 3x3
+ * K-split kernels use 4 waves instead of 8; 4: no K split across workgroups; 8: no tail split; 16: low-resolution 1x1
+ * convolutions on the plain kernel.  DT_CONV_THROUGHPUT below is the combination measured best with 4 keyframes in flight.
+ * Results are unchanged up to the fp32 summation order of the K splits (same products).  Process-wide; returns the mask in force. */
+#define DT_CONV_LATENCY 0
+#define DT_CONV_THROUGHPUT 11
+int dt_conv_set_plan_objective(int mask);
 /* Winograd F(2x2,3x3) variant for 3x3 stride-1 convolutions (2.25x fewer multiplies; same fp32
  * arithmetic type, different summation order: results agree with dt_conv2d_f32 to ~1e-6 relative).
  * packed_w: dt_conv_wino_pack_floats floats made by dt_conv_wino_pack_f32 from the OIHW weight. */

@@ -461,3 +461,46 @@ def test_split_precision_winograd_conv_matches_the_fp32_kernels(shape):
         assert float((got - want).abs().max()) < 3e-6 * scale, (act, float((got - want).abs().max()))
         assert float((got - simple).abs().max()) < 6e-6 * scale
         assert float((want - simple).abs().max()) < 6e-6 * scale
+
+
+@pytest.mark.parametrize("mask", [11, 31])
+def test_throughput_plan_objective_computes_the_same_graph(mask):
+    """dt_conv_set_plan_objective (round 5): with several keyframes in flight the launchers give up the in-workgroup /
+    cross-workgroup K splits that only buy single-launch latency.  Same products, possibly another fp32 summation order:
+    the small-model graph at full bench size must agree with the latency plan to rounding and both with the reference golden
+    at the small size; the setter returns the mask in force and 0 restores the default."""
+    import gpu_util as gu
+    from doubletake_amd.modules import conv_ops as ops
+    from doubletake_amd.modules.networks import CVEncoder
+    from doubletake_amd.modules.networks_fast import SkipDecoderRegression
+
+    g = load_golden("networks.npz")
+    enc = [64, 64, 128, 256, 512]
+    cve = CVEncoder(D, enc[1:], [64, 128, 256, 384]).to(gu.dev())
+    gu.set_formula_weights(cve, 1234)
+    dec = SkipDecoderRegression([enc[0], 64, 128, 256, 384]).to(gu.dev())
+    gu.set_formula_weights(dec, 2345)
+
+    def run(h0, w0, seed):
+        vol = _t(syn.hash_normalish((1, D, h0, w0), seed))
+        feats = [_t(f) for f in syn.prior_pyramid(1, enc, 2 * h0, 2 * w0, 555)]
+        outs = cve(vol, feats[1:])
+        dout = dec([feats[0]] + outs)
+        torch.cuda.synchronize()
+        return outs, dout
+
+    try:
+        assert ops.set_plan_objective(ops.PLAN_LATENCY) == 0
+        lat_small, lat_big = run(H0, W0, 4321), run(120, 160, 77)
+        assert ops.set_plan_objective(mask) == mask
+        thr_small, thr_big = run(H0, W0, 4321), run(120, 160, 77)
+    finally:
+        assert ops.set_plan_objective(ops.PLAN_LATENCY) == 0
+    for i, o in enumerate(thr_small[0]):
+        np.testing.assert_allclose(_np(o), g[f"cve_small_out{i}"], atol=1e-4, rtol=0)
+    for k, v in thr_small[1].items():
+        np.testing.assert_allclose(_np(v), g[f"skip_{k}"], atol=3e-4, rtol=0)
+    for (a, b) in list(zip(lat_big[0], thr_big[0])) + [(lat_big[1][k], thr_big[1][k]) for k in lat_big[1]]:
+        scale = max(a.abs().max().item(), 1.0)
+        assert (a - b).abs().max().item() < 2e-5 * scale
+    assert ops.PLAN_THROUGHPUT == 11 and ops.WINO_MIN_BLOCKS == 96  # (restored with the latency plan)
