@@ -259,12 +259,9 @@ __global__ __launch_bounds__(64 * kDotWaves, DT_DOT_OCC) void cv_dot_lds_kernel(
           ViewProj q;
           {
             const float qx = depth * pa[0] + pt[0], qy = depth * pa[1] + pt[1], qz = depth * pa[2] + pt[2];
-            q.z = qz + 1e-8f;
-            const float sc = (fabsf(qz) > 1e-8f) ? (1.0f / q.z) : 1.0f;  // Project3D (utils/geometry_utils.py:82-93)
-            q.u = qx * sc;
-            q.v = qy * sc;
+            project_scale(qx, qy, qz, q);  // Project3D (utils/geometry_utils.py:82-93), reciprocal by v_rcp + Newton
           }
-          const Taps t = bilinear_taps(q.u, q.v, h, w, inv_w, inv_h);
+          const Taps t = bilinear_taps<true>(q.u, q.v, h, w, inv_w, inv_h);
           sm.w00 = t.w00; sm.w01 = t.w01; sm.w10 = t.w10; sm.w11 = t.w11;
           sm.z = q.z;
           sm.need = (t.w00 != 0.f) || (t.w01 != 0.f) || (t.w10 != 0.f) || (t.w11 != 0.f);

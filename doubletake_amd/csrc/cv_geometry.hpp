@@ -42,6 +42,43 @@ __device__ __forceinline__ ViewProj project_view(PT P, float X, float Y, float Z
   return r;
 }
 
+// ---- round 5: the same geometry with fewer vector instructions (the tuned dot-product and MLP volume kernels) -----------------
+// On gfx950 every vector instruction beside fp32 MFMAs costs matrix time, and the dot-product kernel is bound by their issue
+// rate (bench.py: roofline_warp_match_dot.bound_by).  Two algebraic shortcuts, both far inside the parity budget (numpy
+// oracle with the same substitution on a golden-sized case: matching-MLP volume changes by <= 3.3e-6 against its 5e-5 tolerance,
+// dot-product volume by 5.5e-5 on a range of +-20):
+//   * 1 / z' as v_rcp_f32 + one Newton step (<= 1 ulp; IEEE division is ~10 instructions, this is 3);
+//   * grid_sample's index ((2 u / w - 1 + 1) w - 1) / 2 is u - 0.5 (8 instructions -> 2; differs by rounding only).
+// The stand-alone warp_features kernel, the masks and the general (one thread per output) kernels keep the exact forms above.
+#ifndef DT_FAST_GEOM
+#define DT_FAST_GEOM 1
+#endif
+__device__ __forceinline__ float fast_rcp(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ void project_scale(float qx, float qy, float qz, ViewProj& r) {
+  r.z = qz + 1e-8f;
+  const float s = (fabsf(qz) > 1e-8f) ? (DT_FAST_GEOM ? fast_rcp(r.z) : 1.0f / r.z) : 1.0f;
+  r.u = qx * s;
+  r.v = qy * s;
+}
+template <class PT>
+__device__ __forceinline__ ViewProj project_view_fast(PT P, float X, float Y, float Z) {
+  const float qx = P[0] * X + P[1] * Y + P[2] * Z + P[3];
+  const float qy = P[4] * X + P[5] * Y + P[6] * Z + P[7];
+  const float qz = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+  ViewProj r;
+  project_scale(qx, qy, qz, r);
+  return r;
+}
+// pixel index of grid_sample(align_corners=False) for source pixel coordinate u (pixel centres at +0.5)
+__device__ __forceinline__ float sample_index(float u, float size, float inv_size) {
+  if (DT_FAST_GEOM) return u - 0.5f;
+  const float g = 2.0f * u * inv_size - 1.0f;
+  return ((g + 1.0f) * size - 1.0f) * 0.5f;
+}
+
 // Bilinear tap set for one sample: base texel (x0,y0), 4 weights already zeroed for
 // out-of-bounds taps, and clamped in-bounds addresses so that loads are always legal.
 struct Taps {
@@ -49,11 +86,18 @@ struct Taps {
   float w00, w01, w10, w11;   // (y0,x0) (y0,x1) (y1,x0) (y1,x1); 0 where the tap is outside
 };
 
+template <bool FAST = false>
 __device__ __forceinline__ Taps bilinear_taps(float u, float v, int h, int w, float inv_w, float inv_h) {
-  const float gx = 2.0f * u * inv_w - 1.0f;
-  const float gy = 2.0f * v * inv_h - 1.0f;
-  const float ix = ((gx + 1.0f) * (float)w - 1.0f) * 0.5f;
-  const float iy = ((gy + 1.0f) * (float)h - 1.0f) * 0.5f;
+  float ix, iy;
+  if (FAST) {
+    ix = sample_index(u, (float)w, inv_w);
+    iy = sample_index(v, (float)h, inv_h);
+  } else {
+    const float gx = 2.0f * u * inv_w - 1.0f;
+    const float gy = 2.0f * v * inv_h - 1.0f;
+    ix = ((gx + 1.0f) * (float)w - 1.0f) * 0.5f;
+    iy = ((gy + 1.0f) * (float)h - 1.0f) * 0.5f;
+  }
   Taps t;
   // Anything that cannot touch the image (incl. NaN/inf) samples zero: such a sample gets the base texel -2, for which every
   // tap fails the unsigned range tests below.  The 1-D weights are zeroed per axis BEFORE the four products (0 * finite == +0,

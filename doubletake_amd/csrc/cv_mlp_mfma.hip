@@ -107,16 +107,14 @@ __device__ __forceinline__ void issue_view(ViewData& v, cfloat_ptr vp,
 #ifndef DT_MABL
 #define DT_MABL 0
 #endif
-  const ViewProj q = project_view(vp, X, Y, Z);
+  const ViewProj q = project_view_fast(vp, X, Y, Z);
   // Tap logic of bilinear_taps() (cv_geometry.hpp) with fewer vector instructions -- on gfx950 every vector instruction
   // beside the fp32 MFMAs costs matrix time (scripts/mfma_filler_bench.hip: 3-5.5 cycles each; the fp32 matrix and vector
   // pipes are not independent), so this kernel counts them.  Same results: a sample that cannot touch the image (incl.
   // NaN / inf) gets the base texel -2, for which every tap fails the unsigned range test below; 1-D weights are zeroed
   // per axis BEFORE the four products (0 * finite == +0 == the reference's zeroed tap).
-  const float gx = 2.0f * q.u * inv_w - 1.0f;
-  const float gy = 2.0f * q.v * inv_h - 1.0f;
-  const float ix = ((gx + 1.0f) * (float)w - 1.0f) * 0.5f;
-  const float iy = ((gy + 1.0f) * (float)h - 1.0f) * 0.5f;
+  const float ix = sample_index(q.u, (float)w, inv_w);  // (round 5: u - 0.5, see cv_geometry.hpp)
+  const float iy = sample_index(q.v, (float)h, inv_h);
   const bool any = (ix > -1.0f) & (ix < (float)w) & (iy > -1.0f) & (iy < (float)h);
   const float fx = floorf(ix), fy = floorf(iy);
   int x0 = any ? (int)fx : -2, y0 = any ? (int)fy : -2;
