@@ -787,6 +787,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, timed=True)
+    host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3  # host time to ENQUEUE a step (no wait for the GPU in the loop)
     if fuser is not None and args.tsdf_mode == "slab":
         # slab mode: the replicas are completed by ONE gather of the x-slabs per pass -- inside the timed region, so that the
         # mode is charged for it (on the stream that ran the last integration)
@@ -837,6 +838,7 @@ def main():
         t1 = time.perf_counter()
         for i in range(args.steps):
             step(first_frame + 2 * max(1, n_streams) + i, timed=True)
+        leg_issue_ms = (time.perf_counter() - t1) / args.steps * 1e3
         torch.cuda.synchronize(device)
         if use_dist:
             dist.barrier()
@@ -851,7 +853,7 @@ def main():
         bb = [e for tag, e, _ in ev if tag == "mlp_begin"]
         ee = [e for tag, e, _ in ev if tag == "mlp_end"]
         mm = [e for tag, e, _ in ev if tag == "model_end"]
-        leg = {"streams": max(1, n_streams), "conv_plan_mask": leg_plan, "value": args.steps * CFG["batch"] * world / el, "ms_per_step": el / args.steps * 1e3,
+        leg = {"streams": max(1, n_streams), "conv_plan_mask": leg_plan, "host_issue_ms_per_step": leg_issue_ms, "value": args.steps * CFG["batch"] * world / el, "ms_per_step": el / args.steps * 1e3,
                "dominant_kernel_avg_launch_ms": float(np.mean([x.elapsed_time(y) for x, y in zip(bb, ee)])) if bb else None}
         if mm:
             leg["conv_stack_avg_ms"] = float(np.mean([x.elapsed_time(y) for x, y in zip(ee, mm)]))
@@ -930,6 +932,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            # host time to enqueue one step (Python + ctypes + HIP launch calls of ~50 kernels; the loop never waits for the GPU):
+            # while it stays below ms_per_step the run is GPU-bound
+            "host_issue_ms_per_step": host_issue_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

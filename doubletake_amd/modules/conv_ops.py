@@ -63,7 +63,7 @@ def packed_weight(conv: nn.Conv2d, device, transposed=False):
     """Device buffer with conv.weight re-packed for the MFMA kernel; cached per weight version.
     transposed: pack W.transpose(2, 3) (for launches with dt_conv_desc.transposed = 1)."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, str(device))
+    key = (w.data_ptr(), w._version, device)
     slot = "_dt_pack_t" if transposed else "_dt_pack"
     hit = getattr(conv, slot, None)
     if hit is not None and hit[0] == key:
@@ -104,7 +104,7 @@ def _want_transposed(L, d) -> bool:
 def packed_weight_wino(conv: nn.Conv2d, device):
     """Winograd-domain weights (G g G^T) of a 3x3 conv, packed for conv_wino_kernel; cached per weight version."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, str(device))
+    key = (w.data_ptr(), w._version, device)
     hit = getattr(conv, "_dt_pack_wino", None)
     if hit is not None and hit[0] == key:
         _abi.wait_ready(hit[2], device)
@@ -124,7 +124,7 @@ def packed_weight_wino(conv: nn.Conv2d, device):
 def packed_weight_wino_split(conv: nn.Conv2d, device):
     """Winograd-domain weights as fp16 hi/lo fragments for the opt-in split-precision kernel; cached per weight version."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, str(device))
+    key = (w.data_ptr(), w._version, device)
     hit = getattr(conv, "_dt_pack_wino_split", None)
     if hit is not None and hit[0] == key:
         _abi.wait_ready(hit[2], device)
@@ -184,8 +184,8 @@ def _dev_param(conv, name, device):
     if p is None:
         return None
     if p.device == device and p.dtype == torch.float32 and p.is_contiguous():
-        return p.detach()
-    key = (p.data_ptr(), p._version, str(device))
+        return p  # (only its address is used)
+    key = (p.data_ptr(), p._version, device)
     cache = conv.__dict__.setdefault("_dt_small", {})
     hit = cache.get(name)
     if hit is not None and hit[0] == key:
@@ -196,15 +196,20 @@ def _dev_param(conv, name, device):
     return val
 
 
-def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
-    """Fused conv on NHWC tensors.
-
-    srcs: list of (tensor [n,c,h,w] channels_last, upsample_nearest_x2: bool), concatenated
-    along channels in order.  Returns a channels_last tensor [n, c_out, h_out, w_out].
-    """
-    L = _abi.lib()
+def _conv_plan(srcs, conv, act, impl, L):
+    """Everything about a conv2d call that depends only on the conv module and the sources' shapes / strides / dtypes --
+    validation, the launch descriptor, the kernel choice, the FLOP count -- computed once and cached on the module (the host
+    enqueues ~45 conv launches per keyframe; with 4 keyframes in flight it needs 85 % of a step for that, so the per-call
+    Python work is kept to key construction, one allocation and the ctypes call).  The key carries the strides and dtypes, so a
+    hit implies the same NHWC fp32 layout that was validated on the miss."""
+    key = (act, impl, WINO_MIN_BLOCKS, CONV_PRECISION, tuple((t.shape, t.stride(), t.dtype, up) for t, up in srcs))
+    cache = conv.__dict__.get("_dt_plans")
+    if cache is None:
+        cache = conv.__dict__["_dt_plans"] = {}
+    hit = cache.get(key)
+    if hit is not None:
+        return hit
     x0, up0 = srcs[0]
-    dev = x0.device
     n = x0.shape[0]
     h_in = x0.shape[2] * (2 if up0 else 1)
     w_in = x0.shape[3] * (2 if up0 else 1)
@@ -218,7 +223,6 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
     pad = k // 2
     d.h_out = (h_in + 2 * pad - k) // st + 1
     d.w_out = (w_in + 2 * pad - k) // st + 1
-    ptrs = [None, None, None]
     ctot = 0
     for i, (t, up) in enumerate(srcs):
         if not _is_nhwc(t):
@@ -228,16 +232,9 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
             raise ValueError(f"source {i} extent {(hh, ww)} does not match {(h_in, w_in)}")
         d.c[i] = t.shape[1]
         d.up[i] = 1 if up else 0
-        ptrs[i] = _abi.ptr(t)
         ctot += t.shape[1]
     if ctot != conv.in_channels:
         raise ValueError(f"conv expects {conv.in_channels} input channels, sources provide {ctot}")
-    out = empty_nhwc(n, co, d.h_out, d.w_out, dev)
-    bias = _dev_param(conv, "bias", dev)
-    if residual is not None and (not _is_nhwc(residual) or tuple(residual.shape) != tuple(out.shape)):
-        raise ValueError("residual must be NHWC with the output's shape")
-    stream = _abi.current_stream(dev)
-    _account(2.0 * n * d.h_out * d.w_out * co * ctot * k * k)
     if impl == "mfma" and (co % 32 != 0 or any(d.c[i] % 8 != 0 for i in range(len(srcs)))):
         # channel counts the 32-channel x 8-channel-group MFMA tiling cannot express (the reference's own
         # configurations never produce them): the general-shape kernel, same fused epilogue
@@ -247,22 +244,56 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
         impl = "wino"
     if impl == "wino" and CONV_PRECISION == "split16" and wino_blocks >= SPLIT_MIN_BLOCKS \
             and conv.padding_mode in ("zeros", "replicate") and L.dt_conv2d_wino_split_supported(C.byref(d)):
-        wp = packed_weight_wino_split(conv, dev)
-        _abi.check(L.dt_conv2d_wino_split_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wp), _abi.ptr(bias),
-                                              _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_wino_split_f32")
-    elif impl == "wino":
-        wp = packed_weight_wino(conv, dev)
-        _abi.check(L.dt_conv2d_wino_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wp), _abi.ptr(bias),
-                                        _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_wino_f32")
-    elif impl == "mfma":
+        impl = "wino_split"
+    if impl == "mfma":
         d.transposed = 1 if _want_transposed(L, d) else 0
+    plan = (d, C.byref(d), impl, (n, co, d.h_out, d.w_out), 2.0 * n * d.h_out * d.w_out * co * ctot * k * k)
+    cache[key] = plan
+    return plan
+
+
+def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
+    """Fused conv on NHWC tensors.
+
+    srcs: list of (tensor [n,c,h,w] channels_last, upsample_nearest_x2: bool), concatenated
+    along channels in order.  Returns a channels_last tensor [n, c_out, h_out, w_out].
+    """
+    L = _abi.lib()
+    d, dref, impl, oshape, flops = _conv_plan(srcs, conv, act, impl, L)
+    dev = srcs[0][0].device
+    nsrc = len(srcs)
+    p0 = srcs[0][0].data_ptr()
+    p1 = srcs[1][0].data_ptr() if nsrc > 1 else None
+    p2 = srcs[2][0].data_ptr() if nsrc > 2 else None
+    out = torch.empty(oshape, device=dev, dtype=torch.float32, memory_format=torch.channels_last)
+    bias = _dev_param(conv, "bias", dev)
+    pres = None
+    if residual is not None:
+        if not _is_nhwc(residual) or residual.shape != out.shape:
+            raise ValueError("residual must be NHWC with the output's shape")
+        pres = residual.data_ptr()
+    pbias = None if bias is None else bias.data_ptr()
+    stream = _abi.current_stream(dev)
+    if ACCOUNT is not None:
+        _account(flops)
+    if impl == "wino":
+        wp = packed_weight_wino(conv, dev)
+        rc = L.dt_conv2d_wino_f32(dref, p0, p1, p2, wp.data_ptr(), pbias, pres, out.data_ptr(), stream)
+        if rc:
+            _abi.check(rc, "dt_conv2d_wino_f32")
+    elif impl == "mfma":
         wp = packed_weight(conv, dev, transposed=bool(d.transposed))
-        _abi.check(L.dt_conv2d_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wp), _abi.ptr(bias),
-                                   _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_f32")
+        rc = L.dt_conv2d_f32(dref, p0, p1, p2, wp.data_ptr(), pbias, pres, out.data_ptr(), stream)
+        if rc:
+            _abi.check(rc, "dt_conv2d_f32")
+    elif impl == "wino_split":
+        wp = packed_weight_wino_split(conv, dev)
+        _abi.check(L.dt_conv2d_wino_split_f32(dref, p0, p1, p2, wp.data_ptr(), pbias, pres, out.data_ptr(), stream),
+                   "dt_conv2d_wino_split_f32")
     else:
         wd = _dev_param(conv, "weight", dev)
-        _abi.check(L.dt_conv2d_simple_f32(C.byref(d), ptrs[0], ptrs[1], ptrs[2], _abi.ptr(wd), _abi.ptr(bias),
-                                          _abi.ptr(residual), _abi.ptr(out), stream), "dt_conv2d_simple_f32")
+        _abi.check(L.dt_conv2d_simple_f32(dref, p0, p1, p2, wd.data_ptr(), pbias, pres, out.data_ptr(), stream),
+                   "dt_conv2d_simple_f32")
     return out
 
 
@@ -353,7 +384,7 @@ def _head_pack(head: nn.Sequential, dev):
 
     ca, cb_, cc = head[0], head[2], head[4]
     params = [ca.weight, ca.bias, cb_.weight, cb_.bias, cc.weight, cc.bias]
-    key = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+    key = (dev,) + tuple((p.data_ptr(), p._version) for p in params)
     hit = head.__dict__.get("_dt_head_pack")
     if hit is None or hit[0] != key:
         arrs = [p.detach().float().cpu().numpy() for p in params]
