@@ -49,7 +49,19 @@ constexpr int kStageFloats = 256;  // per wave: 32 pixels x 8 planes of finished
 constexpr int kMaxSrcMfma = 7;     // LDS budget: 12*K + 64 + ~1 KB <= 160 KB
 constexpr int kMaxSrcStream = 15;  // with the views beyond the seventh streamed from global memory (STREAM instantiation)
 
-__host__ __device__ inline int mlp_w1dyn_floats(int K) { return K * kStepsPerView * kStepFloats; }
+// First plane-dependent layer-1 step of source view k (mirrors mlp_pack.view_step_base).  Round 5: a view has 7 plane-dependent
+// metadata inputs (mask, z', dot, angle, source ray xyz) = 3.5 two-slot K steps.  View 0 keeps four steps (its spare slot
+// carries the plane depth); the further views are PAIRED (1,2), (3,4), ...: the first of a pair runs four steps whose last slot
+// carries its partner's mask -- known by then: the next view has already been projected for the prefetch --, the second three.
+// 25 instead of 28 metadata steps at K = 7: 12 MFMAs less per (tile, plane), 3 KB less LDS.  An unpaired last view keeps four.
+#ifndef DT_MLP_PAIR_META
+#define DT_MLP_PAIR_META 1  // (0: four metadata steps for every view, the layout of rounds 1-4; A/B switch -- the host packs for
+#endif                      //  whichever layout dt_cv_mlp_pack_floats reports)
+__host__ __device__ inline int mlp_view_step_base(int k) {
+  if (!DT_MLP_PAIR_META) return k * kStepsPerView;
+  return k <= 0 ? 0 : kStepsPerView + (2 * kStepsPerView - 1) * ((k - 1) / 2) + (((k - 1) & 1) ? kStepsPerView : 0);
+}
+__host__ __device__ inline int mlp_w1dyn_floats(int K) { return mlp_view_step_base(K) * kStepFloats; }
 __host__ __device__ inline int mlp_w1pix_floats(int K) { return (kPixFixed + 2 * K) * kStepFloats; }
 constexpr int kW2Floats = kW2Steps * kStepFloats;
 
@@ -413,6 +425,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc1[i] = accp[i];
 
+      int wstep = 0;  // first layer-1 step of view k (wave-uniform; mlp_view_step_base(k) without the division)
       for (int k = 0; k < K; ++k) {
         float f[8];
         f[0] = v.t00a.x * v.w00 + v.t01a.x * v.w01 + v.t10a.x * v.w10 + v.t11a.x * v.w11;
@@ -451,7 +464,18 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
         const float dot = dotp + __shfl_xor(dotp, 32, 64);
         const float m = (vz > 0.f) ? 1.f : 0.f;
 
-        // the 12 K steps of view k against its layer-1 fragments (WL: LDS for resident views, global memory for streamed ones)
+        // the K steps of view k against its layer-1 fragments (WL: LDS for resident views, global memory for streamed ones):
+        // 8 feature steps, three metadata steps (z'|dot, angle|ray.x, ray.y|ray.z) and -- except for the second view of a
+        // metadata pair (2, 4, 6, ...) -- a fourth one carrying the view's mask beside the plane depth (view 0), the NEXT
+        // view's mask (first of a pair: v already holds view k + 1 of this plane) or nothing (unpaired last view).
+        // (the pair flags come from an opaque copy of k: derived from k itself the compiler clones the whole view loop per
+        //  parity and spills 69 registers)
+        int kq = k;
+        asm volatile("" : "+s"(kq));
+        const bool pair_second = DT_MLP_PAIR_META && (kq >= 2) && !(kq & 1);
+        const bool pair_first = DT_MLP_PAIR_META && (kq & 1) && (kq + 1 < K);
+        const float m_next = (v.z > 0.f) ? 1.f : 0.f;
+        const float spare = (kq == 0) ? depth : (pair_first ? m_next : 0.f);
 #define DT_L1_VIEW(WL)                                                              \
   do {                                                                              \
     if (tile_sees_view) {                                                           \
@@ -462,32 +486,33 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
     }                                                                               \
     {                                                                               \
       const float4 a4 = (WL)[8 * (kStepFloats / 4)];                                \
-      const float bv = half ? vz : m;                                               \
+      const float bv = half ? dot * m : vz;                                         \
       DT_MFMA4(acc1, a4, bv);                                                       \
     }                                                                               \
     {                                                                               \
       const float4 a4 = (WL)[9 * (kStepFloats / 4)];                                \
-      const float bv = half ? vang : dot * m;                                       \
+      const float bv = half ? vsx : vang;                                           \
       DT_MFMA4(acc1, a4, bv);                                                       \
     }                                                                               \
     {                                                                               \
       const float4 a4 = (WL)[10 * (kStepFloats / 4)];                               \
-      const float bv = half ? vsy : vsx;                                            \
+      const float bv = half ? vsz : vsy;                                            \
       DT_MFMA4(acc1, a4, bv);                                                       \
     }                                                                               \
-    {                                                                               \
+    if (!pair_second) {                                                             \
       const float4 a4 = (WL)[11 * (kStepFloats / 4)];                               \
-      const float bv = half ? ((k == 0) ? depth : 0.f) : vsz;                       \
+      const float bv = half ? spare : m;                                            \
       DT_MFMA4(acc1, a4, bv);                                                       \
     }                                                                               \
   } while (0)
         if (!STREAM || k < K_lds) {
-          const float4* wl = reinterpret_cast<const float4*>(lds_w1 + (size_t)k * kStepsPerView * kStepFloats + lane_off);
+          const float4* wl = reinterpret_cast<const float4*>(lds_w1 + (size_t)wstep * kStepFloats + lane_off);
           DT_L1_VIEW(wl);
         } else {
-          const float4* wg = reinterpret_cast<const float4*>(a.w1dyn + (size_t)k * kStepsPerView * kStepFloats + lane_off);
+          const float4* wg = reinterpret_cast<const float4*>(a.w1dyn + (size_t)wstep * kStepFloats + lane_off);
           DT_L1_VIEW(wg);
         }
+        wstep += pair_second ? kStepsPerView - 1 : kStepsPerView;
 #undef DT_L1_VIEW
       }
 

@@ -22,6 +22,8 @@ library cannot be loaded.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import os
 
@@ -318,7 +320,14 @@ class FeatureVolumeManager(CostVolumeManager):
         arrs = [a.float().cpu().numpy() for a in self._mlp_arrays(self.mlp)]
         val = {}
         if self.num_source_views <= self.MAX_FUSED_VIEWS and self.matching_dim_size == 16:
-            packed = mlp_pack.pack_mlp(*arrs, self.num_source_views)
+            # (the metadata-step layout is a build property of the library: ask it how many layer-1 floats it expects)
+            n_dyn = C.c_int(0)
+            _abi.check(_abi.lib().dt_cv_mlp_pack_floats(self.num_source_views, C.byref(n_dyn), None, None, None),
+                       "dt_cv_mlp_pack_floats")
+            paired = n_dyn.value == mlp_pack.dyn_steps_total(self.num_source_views, True) * 256
+            if not paired and n_dyn.value != mlp_pack.dyn_steps_total(self.num_source_views, False) * 256:
+                raise _abi.DoubletakeHipError(f"library expects {n_dyn.value} packed layer-1 floats: unknown step layout")
+            packed = mlp_pack.pack_mlp(*arrs, self.num_source_views, paired=paired)
             val = {n: torch.from_numpy(v).to(device) for n, v in packed.items()}
         raw = self._mlp_arrays(self.mlp)
         val["raw"] = [_f32c(a.to(device)) for a in raw]

@@ -47,18 +47,42 @@ class Columns:
         self.total = o
 
 
-def dyn_step_columns(K):
-    """[K*12, 2] column index fed by half 0 / half 1 at every plane-dependent layer-1 step."""
+def view_step_base(k, paired=True):
+    """First plane-dependent layer-1 step of source view k (= dt::mlp_view_step_base in csrc/cv_mlp_mfma.hip).
+    Round 5: a view has 7 plane-dependent metadata inputs (mask, z', dot, angle, source ray xyz), i.e. 3.5 two-slot K steps.
+    Every view runs the same three steps (z'|dot, angle|ray.x, ray.y|ray.z); the mask rides in a fourth step whose other slot
+    carries the plane depth (view 0) or the mask of the NEXT view -- the further views are PAIRED (1,2), (3,4), ..., and the
+    partner's mask is already known when the step is issued: the kernel has projected the next view by then -- so the second
+    view of a pair has no fourth step.  25 instead of 28 metadata steps at K = 7:
+    12 MFMAs less per (pixel tile, plane) and 3 KB less LDS.  An unpaired last view keeps four steps (one slot unused)."""
+    if k <= 0:
+        return 0
+    if not paired:  # (library built with -DDT_MLP_PAIR_META=0: four metadata steps for every view)
+        return k * STEPS_PER_VIEW
+    return STEPS_PER_VIEW + (2 * STEPS_PER_VIEW - 1) * ((k - 1) // 2) + (STEPS_PER_VIEW if (k - 1) % 2 else 0)
+
+
+def dyn_steps_total(K, paired=True):
+    return view_step_base(K, paired)
+
+
+def dyn_step_columns(K, paired=True):
+    """[dyn_steps_total(K), 2] column index fed by half 0 / half 1 at every plane-dependent layer-1 step."""
     c = Columns(K)
-    tab = np.full((K * STEPS_PER_VIEW, 2), ZERO, dtype=np.int64)
+    tab = np.full((dyn_steps_total(K, paired), 2), ZERO, dtype=np.int64)
     for k in range(K):
-        base = k * STEPS_PER_VIEW
+        base = view_step_base(k, paired)
         for s in range(8):
             tab[base + s] = (c.warp + k * FEAT + s, c.warp + k * FEAT + 8 + s)
-        tab[base + 8] = (c.mask + k, c.z + k)
-        tab[base + 9] = (c.dot + k, c.ang + k)
-        tab[base + 10] = (c.sray + 3 * k + 0, c.sray + 3 * k + 1)
-        tab[base + 11] = (c.sray + 3 * k + 2, c.plane if k == 0 else ZERO)
+        pair_first = paired and k >= 1 and (k & 1) == 1 and k + 1 < K
+        pair_second = paired and k >= 2 and (k & 1) == 0
+        # the same three steps for every view; the seventh value (the mask) rides in a fourth step that the second view of a
+        # pair does not have: (mask_0 | plane depth), (mask_k | mask_k+1) for the first of a pair, (mask_k | -) if unpaired
+        tab[base + 8] = (c.z + k, c.dot + k)
+        tab[base + 9] = (c.ang + k, c.sray + 3 * k + 0)
+        tab[base + 10] = (c.sray + 3 * k + 1, c.sray + 3 * k + 2)
+        if not pair_second:
+            tab[base + 11] = (c.mask + k, c.plane if k == 0 else (c.mask + k + 1 if pair_first else ZERO))
     return tab
 
 
@@ -93,8 +117,9 @@ def _pack_steps(W_ext, tab):
     return np.ascontiguousarray(g, dtype=np.float32)
 
 
-def pack_mlp(W1, b1, W2, b2, W3, b3, K):
-    """numpy in, numpy out: dict(w1dyn, w1pix, w2p, tail) of flat float32 arrays."""
+def pack_mlp(W1, b1, W2, b2, W3, b3, K, paired=True):
+    """numpy in, numpy out: dict(w1dyn, w1pix, w2p, tail) of flat float32 arrays.  paired: the metadata-step layout of the
+    library in use (see view_step_base; callers ask dt_cv_mlp_pack_floats)."""
     W1 = np.asarray(W1, dtype=np.float32)
     cin = Columns(K).total
     if W1.shape != (HID, cin):
@@ -102,7 +127,7 @@ def pack_mlp(W1, b1, W2, b2, W3, b3, K):
     if np.asarray(W2).shape != (HID, HID) or np.asarray(W3).reshape(-1).shape != (HID,):
         raise ValueError("matching MLP must be [Cin,128,128,1]")
     W_ext = np.concatenate([W1, np.zeros((HID, 1), np.float32), np.asarray(b1, np.float32).reshape(HID, 1)], 1)
-    w1dyn = _pack_steps(W_ext, dyn_step_columns(K))
+    w1dyn = _pack_steps(W_ext, dyn_step_columns(K, paired))
     w1pix = _pack_steps(W_ext, pix_step_columns(K))
     # layer 2: step t = block*16 + r, half h feeds input feature acc_feature(block, r, h)
     W2 = np.asarray(W2, dtype=np.float32)
@@ -134,7 +159,7 @@ def pack_hint_mlp(V1, c1, V2, c2, V3, c3):
     return out
 
 
-def emulate_packed_mlp(packed, x_cols, K):
+def emulate_packed_mlp(packed, x_cols, K, paired=True):
     """CPU emulation of the kernel's contraction order from the PACKED weights (used by the
     not-gpu tests to prove the packing tables are a permutation of the reference MLP):
     x_cols [N, Cin] -> matching score [N]."""
@@ -152,7 +177,7 @@ def emulate_packed_mlp(packed, x_cols, K):
                 acc += x_ext[:, cols[s, h]][:, None] * w[None]
         return acc
 
-    acc1 = run(packed["w1pix"], pix_step_columns(K)) + run(packed["w1dyn"], dyn_step_columns(K))
+    acc1 = run(packed["w1pix"], pix_step_columns(K)) + run(packed["w1dyn"], dyn_step_columns(K, paired))
     h1 = np.maximum(acc1, 0.01 * acc1)
     w2 = packed["w2p"].reshape(W2_STEPS, 2, 32, 4)
     tail = packed["tail"]

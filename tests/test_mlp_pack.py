@@ -9,17 +9,21 @@ from oracle import cost_volume_ref as cref
 from oracle import networks_ref as nref
 
 
-@pytest.mark.parametrize("K", [1, 2, 7])
-def test_matching_mlp_pack_is_a_permutation(K):
+@pytest.mark.parametrize("paired", [True, False])
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 7, 8, 12])
+def test_matching_mlp_pack_is_a_permutation(K, paired):
+    """paired = the round-5 layout (metadata of views (1,2), (3,4), ... share a step: 25 instead of 28 metadata steps at K = 7)."""
     cin = syn.mlp_in_channels(K)
     assert cin == mp.Columns(K).total
     p = syn.formula_params(syn.mlp_param_shapes([cin, 128, 128, 1]), 5)
-    packed = mp.pack_mlp(*p, K)
+    packed = mp.pack_mlp(*p, K, paired=paired)
     x = syn.hash_normalish((64, cin), 3)
     want = cref.mlp_forward(x, [(p[0], p[1]), (p[2], p[3]), (p[4], p[5])])[:, 0]
-    np.testing.assert_allclose(mp.emulate_packed_mlp(packed, x, K), want, atol=2e-6)
+    np.testing.assert_allclose(mp.emulate_packed_mlp(packed, x, K, paired=paired), want, atol=2e-6)
+    assert packed["w1dyn"].size == mp.dyn_steps_total(K, paired) * 256
+    assert mp.dyn_steps_total(7, True) == 81 and mp.dyn_steps_total(7, False) == 84
     # every reference column is fed exactly once
-    cols = np.concatenate([mp.dyn_step_columns(K).reshape(-1), mp.pix_step_columns(K).reshape(-1)])
+    cols = np.concatenate([mp.dyn_step_columns(K, paired).reshape(-1), mp.pix_step_columns(K).reshape(-1)])
     used = sorted(c for c in cols.tolist() if c >= 0)
     assert used == list(range(cin))
     assert (cols == mp.BIAS).sum() == 1
