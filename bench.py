@@ -585,9 +585,11 @@ def main():
     ap.add_argument("--conv-precision", choices=("fp32", "split16"), default="fp32",
                     help="arithmetic of the 3x3 stride-1 conv layers: exact fp32 MFMA (default, the headline) or the opt-in "
                          "split-precision Winograd kernel (fp16 hi/lo products on the fp16 matrix pipe, fp32 accumulation)")
-    ap.add_argument("--streams", type=int, default=DEFAULT_STREAMS,
+    ap.add_argument("--streams", type=int, default=None,
                     help="run consecutive keyframes on this many HIP streams (frames are independent in this workload; the "
-                         "TSDF integrations stay in frame order).  The dominant kernel's roofline figure comes from the "
+                         "TSDF integrations stay in frame order).  Default: 4 for the batch-1 configs, 1 for the batched ones (cfg3 "
+                         "batch 8, cfg5 batch 2: a batch already fills the chip and frames in flight only add contention: "
+                         "profiles/r5k_bench_all_configs.txt).  The dominant kernel's roofline figure comes from the "
                          "single-stream leg of the same run (with several frames in flight an event bracket measures the schedule)")
     ap.add_argument("--conv-plan", default="auto",
                     help="plan objective of the conv launchers: 'latency' (one keyframe at a time), 'throughput' (several keyframes "
@@ -616,6 +618,8 @@ def main():
         args.input_sets = 1 if args.graph else 4
     CFG.clear()
     CFG.update(CONFIGS[args.config])
+    if args.streams is None:
+        args.streams = DEFAULT_STREAMS if CFG["batch"] == 1 else 1
     default_cfg = args.config == "cfg2_small"
 
     if args.streams > 3:

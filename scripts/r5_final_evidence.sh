@@ -1,0 +1,27 @@
+#!/bin/bash
+# end-of-round evidence in one gpurun call:  bash scripts/r5_final_evidence.sh TAG
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; TAG=$1; O=gpurun_out/$TAG; mkdir -p $O
+timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "gpu tests rc=$?"; tail -2 $O/pytest_gpu.log
+bash scripts/profile_round.sh ${TAG}p > $O/profile_round.log 2>&1; tail -3 $O/profile_round.log
+cp gpurun_out/${TAG}p/pmc_summary.json profiles/${TAG}_pmc_summary.json 2>/dev/null && python scripts/make_roofline_traffic.py $TAG > /dev/null && cp profiles/roofline_traffic.json $O/roofline_traffic.json && cp profiles/${TAG}_pmc_summary.json $O/
+( cd /tmp && export TMPDIR=/tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/trace_default -o bench -- python $R/bench.py --no-cpu-baseline --no-side-legs > $R/$O/bench_under_default_trace.json 2> /dev/null )
+f=$(find $O/trace_default -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/bench_kernel_stats_default_cmd.csv; rm -rf $O/trace_default
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python - "$O/bench.json" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); r=d["roofline"]
+print("bench: %.1f f/s %.4f ms/step | volume %.4f ms frac %.3f busy %s traffic %s | single %s | parity %s | cpu %.3f f/s" % (d["value"], d["ms_per_step"], r["avg_launch_ms"], r["frac"], r.get("mfma_busy_frac"), r.get("traffic"), d["single_stream"]["ms_per_step"], d["parity"]["ok"], d["cpu_baseline"]["value"]))
+PY
+STEPS=50 bash scripts/bench_all_configs.sh $TAG 2>&1 | tee $O/bench_all_configs.txt
+for cfg in cfg2_small cfg4_small; do
+DT_CONFIG=$cfg DT_MODES=serial,lookahead,graphs timeout 300 python scripts/time_incremental.py > $O/time_incremental_$cfg.json 2>/dev/null; python -c "
+import json; d=json.load(open('$O/time_incremental_$cfg.json'))
+for k,v in d.items():
+    if isinstance(v,dict) and 'wall_ms_per_frame' in v: print('$cfg', k, round(v['wall_ms_per_frame'],3), 'ms/frame; host', round(v['host_issue_ms_per_frame'],3))"
+done
+python bench.py --force-dist --no-cpu-baseline --no-side-legs > $O/bench_forcedist.json 2>/dev/null; python -c "
+import json; d=json.load(open('$O/bench_forcedist.json')); print('force-dist', round(d['value'],1), 'f/s ranks', d['config']['ranks_seen'])"
+python bench.py --force-dist --tsdf-mode slab --tsdf-res 0.02 --no-cpu-baseline --no-side-legs > $O/bench_forcedist_slab.json 2>/dev/null; python -c "
+import json; d=json.load(open('$O/bench_forcedist_slab.json')); print('force-dist slab 0.02', round(d['value'],1), 'f/s')"
+python bench.py --tsdf-res 0.02 --no-cpu-baseline --no-side-legs > $O/bench_replica_002.json 2>/dev/null; python -c "
+import json; d=json.load(open('$O/bench_replica_002.json')); print('replica 0.02', round(d['value'],1), 'f/s')"

@@ -40,8 +40,10 @@ def test_argument_errors_are_reported_not_launched():
     assert b"channels" in L.dt_last_error() or b"null" in L.dt_last_error()
     n = ctypes.c_int()
     assert L.dt_cv_mlp_pack_floats(16, ctypes.byref(n), None, None, None) != 0   # the fused kernel takes 1..15 source views
-    assert L.dt_cv_mlp_pack_floats(9, ctypes.byref(n), None, None, None) == 0 and n.value == 9 * 12 * 256
-    assert L.dt_cv_mlp_pack_floats(7, ctypes.byref(n), None, None, None) == 0 and n.value == 7 * 12 * 256
+    from doubletake_amd.modules import mlp_pack
+
+    assert L.dt_cv_mlp_pack_floats(9, ctypes.byref(n), None, None, None) == 0 and n.value == mlp_pack.dyn_steps_total(9) * 256 == 104 * 256
+    assert L.dt_cv_mlp_pack_floats(7, ctypes.byref(n), None, None, None) == 0 and n.value == 81 * 256
     assert L.dt_conv_pack_floats(64, 64, 3) == 64 * 64 * 9
     d = _abi.ConvDesc()
     assert L.dt_conv2d_f32(ctypes.byref(d), None, None, None, None, None, None, None, None) != 0
