@@ -80,6 +80,8 @@ SIGNATURES = {
     "dt_head_mlp_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "dt_head_mlp_multi_f32": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                    C.POINTER(_P), C.POINTER(_L), C.POINTER(_I), _P]),
+    "dt_conv2d_wino_heads_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _I, C.POINTER(_P), C.POINTER(_P),
+                                      C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_L), C.POINTER(_I), _P]),
     "dt_upsample2x_bilinear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dt_exp_f32": (_I, [_P, _P, _L, _P]),
     "dt_stem_im2col_f32": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "head_device.hpp"
 
 namespace dt {
 
@@ -1060,6 +1061,30 @@ __global__ __launch_bounds__(BodyA::THREADS, (BodyA::THREADS == 256 ? DT_WINO1_W
   if (blockIdx.x < nblocks_a) BodyA::run(a, lds, blockIdx.x, nblocks_a);
   else BodyB::run(b, lds, blockIdx.x - nblocks_a, gridDim.x - nblocks_a);
 }
+// ---- a Winograd convolution with the coarse regression heads as extra workgroups of its grid (round 5) ----------------------
+// SkipDecoderRegression (reference modules/networks_fast.py:134-141): the heads of scales 3, 2, 1 depend on decoder features
+// that are final before the last block's 240x320 convolutions start, and nothing depends on them.  As a launch of their own
+// they cost one workgroup's dependent MFMA chain (36 us for 788 small workgroups) at the end of the stream; here they are the
+// LAST blocks of the conv launch and start as the conv's first round of workgroups drains (1200 blocks on 768 resident slots:
+// the second round is 56 % full).  The launch is bound by slot time either way -- at the conv kernel's 144 registers a head
+// workgroup occupies one of three slots per CU for its whole latency-bound chain, where the stand-alone head kernel (40
+// registers) keeps all 788 resident at once -- so the merge returns 18 us of the 35 on one stream, not all of it; heads in FRONT
+// of the conv blocks fill every slot of the first round and return 9.  Same bodies, hence bit-identical results to two launches.
+__global__ __launch_bounds__(256, DT_WINO1_WPE) void conv_wino_heads_kernel(const ConvArgs a, const HeadMultiArgs m, unsigned nblocks_heads) {
+  __shared__ __attribute__((aligned(16))) float lds_all[8192];
+#ifndef DT_HEADS_FIRST
+#define DT_HEADS_FIRST 0  // (measured, DESIGN 4.2 "Round 5": behind the conv blocks 0.900 ms conv stack, in front of them 0.909, two launches 0.919)
+#endif
+  const unsigned nconv = gridDim.x - nblocks_heads;
+  if (DT_HEADS_FIRST) {
+    if (blockIdx.x < nblocks_heads) head_multi_block(m, blockIdx.x, lds_all, lds_all + 4096);
+    else conv_wino_body<1>(a, lds_all, blockIdx.x - nblocks_heads, nconv);
+  } else {
+    if (blockIdx.x >= nconv) head_multi_block(m, blockIdx.x - nconv, lds_all, lds_all + 4096);
+    else conv_wino_body<1>(a, lds_all, blockIdx.x, nconv);
+  }
+}
+
 template <int KS, int ST, int SPLIT>
 struct MfmaBody {
   static constexpr int THREADS = ConvMfmaCfg<KS, ST, SPLIT>::THREADS;
@@ -1646,6 +1671,36 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
   else
     DT_LAUNCH(conv_wino_kernel<1>, dim3((unsigned)grid), dim3(256), 0, to_stream(s), a);
   return check_launch("dt_conv2d_wino_f32");
+}
+
+/* dt_conv2d_wino_f32 with n_heads fused regression heads (dt_head_mlp_multi_f32's tables) as the first workgroups of the same
+ * launch.  Only for Winograd launches of 256-thread workgroups without a K split across workgroups (the chip-filling layers);
+ * anything else runs as the two launches it replaces.  Results are those of the two launches, bit for bit. */
+int dt_conv2d_wino_heads_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* packed_w,
+                             const float* bias, const float* residual, float* out, int n_heads, const float* const* h_in,
+                             const float* const* h_wa, const float* const* h_wb, const float* const* h_tail, float* const* h_out,
+                             float* const* h_out_exp, const int64_t* h_pixels, const int* h_cin, dt_stream_t s) {
+  ConvArgs a;
+  if (int rc = fill_args(d, in0, in1, in2, bias, residual, out, a, "dt_conv2d_wino_heads_f32")) return rc;
+  DT_REQUIRE(packed_w != nullptr, "dt_conv2d_wino_heads_f32: null weights");
+  DT_REQUIRE(d->ksize == 3 && d->stride == 1 && d->c_out > 0 && d->c_out % 32 == 0,
+             "dt_conv2d_wino_heads_f32: a 3x3 stride-1 convolution with c_out %% 32 == 0 (k=%d s=%d c_out=%d)", d->ksize, d->stride, d->c_out);
+  HeadMultiArgs m;
+  unsigned head_blocks = 0;
+  if (int rc = head_multi_fill(n_heads, h_in, h_wa, h_wb, h_tail, h_out, h_out_exp, h_pixels, h_cin, m, head_blocks,
+                               "dt_conv2d_wino_heads_f32")) return rc;
+  a.wp = packed_w;
+  const long wt_x = (a.w_out + 2 * kWinoTW - 1) / (2 * kWinoTW), wt_y = (a.h_out + 2 * kWinoTH - 1) / (2 * kWinoTH);
+  const long blocks = (long)a.n * wt_y * wt_x * a.co_blocks;
+  const int cus = device_cus();
+  static const int fuse_on = [] { const char* e = getenv("DT_HEADS_IN_CONV"); return e ? atoi(e) : 1; }();
+  if (!fuse_on || blocks < 2L * cus || blocks + head_blocks >= 2147483647L) {
+    // a launch that does not fill the chip (K split inside / across workgroups): the two launches it would replace
+    if (int rc = dt_conv2d_wino_f32(d, in0, in1, in2, packed_w, bias, residual, out, s)) return rc;
+    return dt_head_mlp_multi_f32(n_heads, h_in, h_wa, h_wb, h_tail, h_out, h_out_exp, h_pixels, h_cin, s);
+  }
+  DT_LAUNCH(conv_wino_heads_kernel, dim3((unsigned)(blocks + head_blocks)), dim3(256), 0, to_stream(s), a, m, head_blocks);
+  return check_launch("dt_conv2d_wino_heads_f32");
 }
 
 // kernel the single-launch entry points would pick (kept in one place so that the pair launcher agrees with them)

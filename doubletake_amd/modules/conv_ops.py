@@ -420,6 +420,45 @@ def head_mlp_multi(xs, heads, with_exp=False):
     return [(o, e) for o, e in zip(outs, outs_e)] if with_exp else outs
 
 
+#: run the coarse regression heads as workgroups of the last decoder block's first convolution (dt_conv2d_wino_heads_f32;
+#: DT_HEADS_IN_CONV=0 restores the two launches: A/B switch, results are bit-identical either way)
+HEADS_IN_CONV = _os.environ.get("DT_HEADS_IN_CONV", "1") != "0"
+
+
+def conv2d_with_heads(srcs, conv: nn.Conv2d, act, xs, heads, with_exp=False):
+    """``conv2d(srcs, conv, act)`` and ``head_mlp_multi(xs, heads, with_exp)`` in ONE launch when the convolution is a
+    chip-filling Winograd layer (otherwise, and for shapes the fused entry does not take, the two calls).  Returns
+    (conv output, list of head results), bit-identical to the two calls."""
+    L = _abi.lib()
+    d, dref, impl, oshape, flops = _conv_plan(srcs, conv, act, "mfma", L)
+    if not (HEADS_IN_CONV and HEAD_MULTI_LAUNCH and impl == "wino" and 1 <= len(xs) <= 4):
+        return conv2d(srcs, conv, act=act), (head_mlp_multi(xs, heads, with_exp=with_exp) if len(xs) >= 2 else
+                                              [head_mlp(x, h, with_exp=with_exp) for x, h in zip(xs, heads)])
+    dev = srcs[0][0].device
+    nsrc = len(srcs)
+    p0 = srcs[0][0].data_ptr()
+    p1 = srcs[1][0].data_ptr() if nsrc > 1 else None
+    p2 = srcs[2][0].data_ptr() if nsrc > 2 else None
+    out = torch.empty(oshape, device=dev, dtype=torch.float32, memory_format=torch.channels_last)
+    bias = _dev_param(conv, "bias", dev)
+    n_h = len(xs)
+    pks = [_head_pack(h, dev) for h in heads]
+    outs = [torch.empty((x.shape[0], 1, x.shape[2], x.shape[3]), device=dev, dtype=torch.float32) for x in xs]
+    outs_e = [torch.empty_like(o) for o in outs] if with_exp else [None] * n_h
+    tab = lambda vals: (C.c_void_p * n_h)(*[_abi.ptr(v) for v in vals])
+    pixels = (C.c_int64 * n_h)(*[x.shape[0] * x.shape[2] * x.shape[3] for x in xs])
+    cin = (C.c_int * n_h)(*[x.shape[1] for x in xs])
+    if ACCOUNT is not None:
+        _account(flops)
+        _account(sum(2.0 * x.shape[0] * x.shape[2] * x.shape[3] * (x.shape[1] * 128 + 128 * 128 + 128) for x in xs))
+    wp = packed_weight_wino(conv, dev)
+    _abi.check(L.dt_conv2d_wino_heads_f32(dref, p0, p1, p2, wp.data_ptr(), None if bias is None else bias.data_ptr(), None,
+                                          out.data_ptr(), n_h, tab(xs), tab([p["wa"] for p in pks]), tab([p["wb"] for p in pks]),
+                                          tab([p["tail"] for p in pks]), tab(outs), tab(outs_e), pixels, cin,
+                                          _abi.current_stream(dev)), "dt_conv2d_wino_heads_f32")
+    return out, ([(o, e) for o, e in zip(outs, outs_e)] if with_exp else outs)
+
+
 def head_mlp(x, head: nn.Sequential, with_exp=False):
     """Fused 1x1 -> ELU -> 1x1 -> ELU -> 1x1 regression head (modules/networks_fast.py:102-132).
     x NHWC [n,c,h,w] (c = 64, 128, or 256 for small maps) -> [n,1,h,w]; with_exp: (out, exp(out)) from the same launch."""

@@ -55,12 +55,32 @@ class SkipDecoder(nn.Module):
                 in_ch=input_channels[bi], out_ch=self.output_channels[bi], skip_chns=input_channels[bi + 1],
                 use_bn=use_bn))
 
-    def _features(self, features, impl="mfma"):
+    def _features(self, features, impl="mfma", coarse_heads=None):
+        """coarse_heads = (results dict, with_exp) -- SkipDecoderRegression only: the heads of scales 3, 2, 1 read features that
+        are final before the last block's 240x320 convolutions start and nothing depends on them, so they are launched as
+        extra workgroups of that block's first convolution (ops.conv2d_with_heads) and their results left in the dict."""
         feats = [ops.as_nhwc(f) for f in features]
         out = {}
         x = feats[-1]
         for bi, scale in ((1, 3), (2, 2), (3, 1), (4, 0)):
-            x = getattr(self, f"block{bi}").run(x, feats[-1 - bi], impl=impl)
+            blk = getattr(self, f"block{bi}")
+            if bi == 4 and coarse_heads is not None and impl == "mfma":
+                results, with_exp = coarse_heads
+                small = [(s, out[f"feature_s{s}_b1hw"], getattr(self, f"out{4 - s}")) for s in (3, 2, 1)]
+                small = [t for t in small if ops.head_mlp_supported(t[1], t[2])
+                         and t[1].shape[0] * t[1].shape[2] * t[1].shape[3] <= ops.HEAD_MULTI_MAX_PIXELS]
+                x = blk.pre_concat_conv.run([(x, False)], impl=impl)
+                post = blk.post_concat_conv
+                if len(small) >= 2:
+                    y, res = ops.conv2d_with_heads([(x, True), (feats[-1 - bi], False)], post.conv1, ops.ACT_ELU,
+                                                   [t[1] for t in small], [t[2] for t in small], with_exp=with_exp)
+                    for t, r in zip(small, res):
+                        results[t[0]] = r
+                else:
+                    y = ops.conv2d([(x, True), (feats[-1 - bi], False)], post.conv1, act=ops.ACT_ELU, impl=impl)
+                x = ops.conv2d([(y, False)], post.conv2, act=ops.ACT_ELU, impl=impl)
+            else:
+                x = blk.run(x, feats[-1 - bi], impl=impl)
             out[f"feature_s{scale}_b1hw"] = x
         return out
 
@@ -83,15 +103,17 @@ class SkipDecoderRegression(SkipDecoder):
         """Reference contract: {log_depth_pred_s{i}_b1hw, ...}.  with_depth (extension used by
         DepthModelCVHint): the head kernels also write depth_pred_s{i}_b1hw = exp(log depth), saving the four
         exp passes of experiment_modules/doubletake_model.py:410-418."""
-        out = self._features(features, impl=_impl)
+        results = {}
+        out = self._features(features, impl=_impl, coarse_heads=(results, with_depth) if _impl == "mfma" else None)
         todo = []
         for oi, scale in ((1, 3), (2, 2), (3, 1), (4, 0)):
             head = getattr(self, f"out{oi}")
             feat = out[f"feature_s{scale}_b1hw"]
             todo.append((scale, feat, head, _impl == "mfma" and ops.head_mlp_supported(feat, head)))
-        # the coarse heads are independent and each far too small to fill the chip: one launch for all of them
-        small = [t for t in todo if t[3] and t[1].shape[0] * t[1].shape[2] * t[1].shape[3] <= ops.HEAD_MULTI_MAX_PIXELS]
-        results = {}
+        # the coarse heads are independent and each far too small to fill the chip: one launch for all of them (round 5: when
+        # _features could place them in the grid of the last block's first convolution, `results` already holds them)
+        small = [t for t in todo if t[3] and t[0] not in results
+                 and t[1].shape[0] * t[1].shape[2] * t[1].shape[3] <= ops.HEAD_MULTI_MAX_PIXELS]
         if ops.HEAD_MULTI_LAUNCH and len(small) >= 2:
             for t, res in zip(small, ops.head_mlp_multi([t[1] for t in small], [t[2] for t in small], with_exp=with_depth)):
                 results[t[0]] = res

@@ -301,6 +301,18 @@ int dt_head_mlp_f32(const float* in_nhwc, const float* wa, const float* wb, cons
 int dt_head_mlp_multi_f32(int n_heads, const float* const* in_nhwc, const float* const* wa,
                           const float* const* wb, const float* const* tail, float* const* out,
                           float* const* out_exp, const int64_t* pixels, const int* cin, dt_stream_t s);
+/* dt_conv2d_wino_f32 and dt_head_mlp_multi_f32 in ONE launch (round 5): SkipDecoderRegression's heads of scales 3, 2, 1
+ * (modules/networks_fast.py:134-141) depend on decoder features that are final before the last block's 240x320 convolutions
+ * start, and nothing depends on them, so their workgroups ride at the front of that convolution's grid instead of waiting at
+ * the end of the stream as a launch of their own (one workgroup's dependent MFMA chain long).  Arguments: those of the two
+ * calls.  Only chip-filling Winograd launches (>= 2 workgroups per CU) are fused; anything else runs as the two launches.
+ * Results are bit-identical to the two launches. */
+int dt_conv2d_wino_heads_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2,
+                             const float* packed_w, const float* bias, const float* residual, float* out,
+                             int n_heads, const float* const* head_in_nhwc, const float* const* head_wa,
+                             const float* const* head_wb, const float* const* head_tail, float* const* head_out,
+                             float* const* head_out_exp, const int64_t* head_pixels, const int* head_cin,
+                             dt_stream_t s);
 /* bilinear x2 upsample, align_corners=False (utils/generic_utils.py:95-104), NHWC. */
 int dt_upsample2x_bilinear_f32(const float* in_nhwc, float* out_nhwc, int n, int h, int w,
                                int c, dt_stream_t s);

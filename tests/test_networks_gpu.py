@@ -504,3 +504,43 @@ def test_throughput_plan_objective_computes_the_same_graph(mask):
         scale = max(a.abs().max().item(), 1.0)
         assert (a - b).abs().max().item() < 2e-5 * scale
     assert ops.PLAN_THROUGHPUT == 11 and ops.WINO_MIN_BLOCKS == 96  # (restored with the latency plan)
+
+
+@pytest.mark.parametrize("h0,w0,with_depth", [(120, 160, True), (96, 128, False), (16, 24, True)])
+def test_coarse_heads_inside_the_conv_grid_are_bit_identical(h0, w0, with_depth):
+    """Round 5 (dt_conv2d_wino_heads_f32): SkipDecoderRegression's heads of scales 3, 2, 1 run as the first workgroups of the
+    last block's first 240x320 convolution instead of as a launch of their own.  Same bodies: every output of the decoder must
+    equal the two-launch path bit for bit, and the step must need one launch less -- at bench size and at the cfg4 size; on a
+    small map (the convolution does not fill the chip) the fused entry falls back to the two launches."""
+    import gpu_util as gu
+    from doubletake_amd import _abi
+    from doubletake_amd.modules import conv_ops as ops
+    from doubletake_amd.modules.networks_fast import SkipDecoderRegression
+
+    enc = [64, 64, 128, 256, 384]
+    dec = SkipDecoderRegression(enc).to(gu.dev())
+    gu.set_formula_weights(dec, 2345)
+    feats = [_t(syn.hash_normalish((1, c, (2 * h0) >> i, (2 * w0) >> i), 70 + i)) for i, c in enumerate(enc)]
+    L = _abi.lib()
+
+    def run(flag):
+        prev = ops.HEADS_IN_CONV
+        ops.HEADS_IN_CONV = flag
+        try:
+            dec(feats, with_depth=with_depth)  # (weight packs)
+            c0 = int(L.dt_kernel_launch_count())
+            out = dec(feats, with_depth=with_depth)
+            torch.cuda.synchronize()
+            return out, int(L.dt_kernel_launch_count()) - c0
+        finally:
+            ops.HEADS_IN_CONV = prev
+
+    fused, n_fused = run(True)
+    plain, n_plain = run(False)
+    assert set(fused) == set(plain)
+    for k in plain:
+        assert torch.equal(fused[k], plain[k]), k
+    assert float(fused["log_depth_pred_s3_b1hw"].abs().max()) > 1e-3
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    blocks = ((2 * h0 + 7) // 8) * ((2 * w0 + 15) // 16) * 2
+    assert n_fused == n_plain - (1 if blocks >= 2 * cus else 0)

@@ -501,3 +501,33 @@ def test_span_plan_scratch_size_is_checked():
     again = m(**args, cv_depth_hint_dict=hd)[0]
     torch.cuda.synchronize()
     assert torch.equal(again, good)
+
+
+def test_cu_budget_only_changes_how_units_are_dealt():
+    """Round 5: dt_cv_mlp_set_cu_budget(n) launches the persistent volume kernel with n workgroups (rounded down to a multiple
+    of 8, at least 8, at most the device's CU count; 0 = the whole device).  Same volume whatever the budget -- planned and
+    un-planned spans, hint and no-hint kernel -- and the setter reports the budget in force."""
+    import gpu_util as gu
+    from doubletake_amd import _abi
+    from doubletake_amd.modules.cost_volume import FeatureMeshHintVolumeManager, FeatureVolumeManager
+
+    L = _abi.lib()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    b, k, h, w, D = 1, 7, 60, 80, 32
+    t = gu.to_dev(syn.volume_inputs(b, k, h, w, 16, 9))
+    try:
+        assert L.dt_cv_mlp_set_cu_budget(0) == cus
+        for cls, kw in ((FeatureMeshHintVolumeManager, dict(cv_depth_hint_dict=gu.hint_dict(t))), (FeatureVolumeManager, {})):
+            m = cls(h, w, num_depth_bins=D, num_source_views=k).to(gu.dev())
+            gu.load_formula_mlp(m.mlp, [syn.mlp_in_channels(k), 128, 128, 1], 3)
+            if kw:
+                gu.load_formula_mlp(m.hint_mlp, [3, 12, 12, 1], 4)
+            assert L.dt_cv_mlp_set_cu_budget(0) == cus
+            ref = m(**gu.volume_call_args(t), **kw)[0].clone()
+            for budget, want in ((cus // 2, cus // 2 // 8 * 8), (13, 8), (100, 96), (10 * cus, cus)):
+                assert L.dt_cv_mlp_set_cu_budget(budget) == want
+                got = m(**gu.volume_call_args(t), **kw)[0]
+                torch.cuda.synchronize()
+                assert float((got - ref).abs().max()) < 2e-6, (cls.__name__, budget)
+    finally:
+        assert L.dt_cv_mlp_set_cu_budget(0) == cus
