@@ -207,7 +207,7 @@ def cpu_baseline(inp, pyr, model, threads="8,all", batched=False):
         value_frame_s, cores = runs[best_other]["frame_s"] * frame8 / runs[8]["frame_s"], best_other
     per = "; ".join(f"{n} threads: frame {r['frame_s']:.2f} s (volume {r['volume_s']:.2f} s)" for n, r in runs.items())
     port_ratio = None
-    try:  # measured in the build container, where the reference can be imported (scripts/cpu_ref_vs_port.py)
+    try:  # measured in the build container, where the reference can be imported (tests/golden/cpu_ref_vs_port.py)
         rv = json.load(open(os.path.join(REPO, "profiles", "r5_cpu_ref_vs_port.json")))
         port_ratio = {"port_over_reference_frame_time": rv["port_over_reference"]["frame_s"], "threads": rv["threads"],
                       "cpu_model": rv["cpu_model"], "reference_frame_s": rv["reference"]["frame_s"], "port_frame_s": rv["port"]["frame_s"],

@@ -16,9 +16,12 @@ from doubletake_amd.utils import synthetic as syn
 def main():
     dev = gu.dev()
     out = {}
+    only = os.environ.get("DT_ENC_ONLY")  # e.g. "1,8": antialiased=True, n=8 only (for a clean kernel trace)
     for aa in (True, False):
         m = ResnetMatchingEncoder(18, 16, pretrained=False, antialiased=aa).to(dev)
         for n in (1, 8):
+            if only and (str(int(aa)), str(n)) != tuple(only.split(",")):
+                continue
             img = torch.from_numpy(syn.hash_normalish((n, 3, 480, 640), 3)).to(dev)
             for _ in range(5):
                 m(img)

@@ -7,7 +7,10 @@ Times, in THIS container (the only place /root/reference exists), on the same co
   (ii) oracle/torch_cpu_ref.py: hint_volume_loop -> lowest_cost -> cv_encoder -> skip_decoder_regression -> exp
 and compares their outputs.  Writes profiles/r5_cpu_ref_vs_port.json.  Not run on the GPU box (reads /root/reference).
 
-    python scripts/cpu_ref_vs_port.py [--threads 8] [--repeats 3]
+    python tests/golden/cpu_ref_vs_port.py [--threads 8] [--repeats 3]
+
+Lives under tests/ because it is checker infrastructure: it imports the oracle (and the reference), which only tests/, smoke()
+and bench.py's cpu_baseline leg may do.
 """
 import argparse
 import contextlib
@@ -19,9 +22,9 @@ import time
 
 import numpy as np
 
-REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, REPO)
-sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.dont_write_bytecode = True
 
 
