@@ -781,6 +781,12 @@ def main():
     if streams is not None:
         for st in streams:
             st.wait_stream(torch.cuda.current_stream(device))
+        # set-up, not warm-up: every stream runs two steps once so that its allocator pool and its per-stream library scratch
+        # exist before the W warm-up steps (with W < 2 x streams a stream would otherwise meet its first hipMalloc inside the
+        # timed region: 770 instead of 788 frames/s at the driver's --steps 20 --warmup 5)
+        for i in range(2 * len(streams)):
+            step(i)
+        torch.cuda.synchronize(device)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(device)
