@@ -575,7 +575,9 @@ __global__ __launch_bounds__(256) void conv_mfma_wshare_kernel(const ConvArgs a)
 // loads its own B fragment (4 consecutive channels) directly, so nothing is staged and eight
 // 8-channel groups (16 dwordx4 loads per lane) are issued before their 32 MFMAs -- with one tap per
 // group there is no other way to cover the load latency.  One wave = one 32-channel x 32-pixel block.
-__device__ __forceinline__ void conv1x1_mfma_body(const ConvArgs& a, unsigned vblock) {
+constexpr int kC1x1Pitch = 36;                       // floats per pixel of the output stage (32 channels + pad: bank spread)
+constexpr int kC1x1LdsFloats = 4 * 32 * kC1x1Pitch;   // four waves x 32 pixels
+__device__ __forceinline__ void conv1x1_mfma_body(const ConvArgs& a, unsigned vblock, float* lds_stage) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, p = lane & 31;
@@ -628,28 +630,42 @@ __device__ __forceinline__ void conv1x1_mfma_body(const ConvArgs& a, unsigned vb
       }
     }
   }
-  if (live) {
-    const size_t pix_off = (size_t)pix * a.c_out;
+  // Epilogue.  The C layout gives lane (pixel p, half h) the channels q*8 + h*4 .. +3 of its pixel: stored from there a wave
+  // instruction writes 64 pieces of 16 bytes, 512 B (= c_out floats) apart -- 9.8 M partial-line writes for the matching encoder's
+  // 64 -> 128 layer at 8 images (round 5 trace: 68 us for 236 MB = 3.5 TB/s).  The block is transposed through a wave-private LDS
+  // stage instead, so that eight consecutive lanes write the 128 contiguous bytes of one pixel's 32 channels: whole lines.
+  float* st = lds_stage + wave * (32 * kC1x1Pitch);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = cb * 32 + q * 8 + half * 4;
-      const size_t off = pix_off + co;
-      float4 o = make_float4(acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
-      if (a.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
-        o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
-      }
-      if (a.res) {
-        const float4 rv = *reinterpret_cast<const float4*>(a.res + off);
-        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
-      }
-      o.x = apply_act(o.x, a.act); o.y = apply_act(o.y, a.act); o.z = apply_act(o.z, a.act); o.w = apply_act(o.w, a.act);
-      *reinterpret_cast<float4*>(a.out + off) = o;
+  for (int q = 0; q < 4; ++q) {
+    const int co = cb * 32 + q * 8 + half * 4;
+    float4 o = make_float4(acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+    if (a.bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+      o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+    }
+    if (a.res && live) {
+      const float4 rv = *reinterpret_cast<const float4*>(a.res + (size_t)pix * a.c_out + co);
+      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
+    o.x = apply_act(o.x, a.act); o.y = apply_act(o.y, a.act); o.z = apply_act(o.z, a.act); o.w = apply_act(o.w, a.act);
+    *reinterpret_cast<float4*>(st + p * kC1x1Pitch + q * 8 + half * 4) = o;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (have_block) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pp = j * 8 + (lane >> 3), ch = (lane & 7) * 4;
+      const long gp = pb * 32 + pp;
+      const float4 o = *reinterpret_cast<const float4*>(st + pp * kC1x1Pitch + ch);
+      if (gp < npix) *reinterpret_cast<float4*>(a.out + (size_t)gp * a.c_out + cb * 32 + ch) = o;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) { conv1x1_mfma_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds_stage[kC1x1LdsFloats];
+  conv1x1_mfma_body(a, blockIdx.x, lds_stage);
+}
 
 // ---- Winograd F(2x2, 3x3) variant of the 3x3 stride-1 conv -------------------------------------------
 // Y = A^T [ (G g G^T) .* (B^T d B) ] A per 4x4 input window / 2x2 output tile: 16 multiplies instead of 36,
@@ -1099,8 +1115,8 @@ struct WinoBody {
 };
 struct OneByOneBody {
   static constexpr int THREADS = 256;
-  static constexpr int LDS_FLOATS = 0;
-  static __device__ __forceinline__ void run(const ConvArgs& a, float*, unsigned vb, unsigned) { conv1x1_mfma_body(a, vb); }
+  static constexpr int LDS_FLOATS = kC1x1LdsFloats;
+  static __device__ __forceinline__ void run(const ConvArgs& a, float* lds, unsigned vb, unsigned) { conv1x1_mfma_body(a, vb, lds); }
 };
 
 // OIHW 3x3 weights -> U = G g G^T per (co, ci), packed [co_block][group][xi][half][32][4]

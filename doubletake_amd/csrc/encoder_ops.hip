@@ -3,6 +3,8 @@
 // The convolutions themselves run on the fp32-MFMA conv primitive (conv.hip); this file holds what
 // sits between them.  All activations are NHWC fp32.  Every kernel here is HBM-bound: one read and
 // one write of the activation, float4 along the channel axis.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace dt {
@@ -111,6 +113,60 @@ __global__ __launch_bounds__(256) void blurpool_kernel(const float* __restrict__
 // ---- MaxPool2d(2, stride 1) + BlurPool(4, stride 2) in one pass (the anti-aliased stem's `maxpool`) ------
 // out(oy,ox) = sum_{ky,kx} filt[ky][kx] * M(reflect(2oy+ky-1), reflect(2ox+kx-1)),  M = 2x2 running max of
 // the (h x w) input, extent (h-1) x (w-1).  One read of the input instead of read+write+read.
+// one output pixel (4 channels) of MaxPool2d(2,1) + BlurPool(4, stride 2); base = image + channel quad
+__device__ __forceinline__ float4 maxblur_one(const float* __restrict__ base, int oy, int ox, int hm, int wm, int w, int c,
+                                              const BlurFilt& filt) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int y0 = oy * 2 - 1, x0 = ox * 2 - 1;
+  if (y0 >= 0 && y0 + 3 < hm && x0 >= 0 && x0 + 3 < wm) {
+    // interior: the 4x4 window of 2x2 maxima comes from a 5x5 input window, walked row by row
+    float4 prev[4];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const float* rp = base + ((size_t)(y0 + r) * w + x0) * c;
+      float4 v[5];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) v[q] = *reinterpret_cast<const float4*>(rp + (size_t)q * c);
+      float4 hm4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        hm4[q] = make_float4(fmaxf(v[q].x, v[q + 1].x), fmaxf(v[q].y, v[q + 1].y), fmaxf(v[q].z, v[q + 1].z),
+                             fmaxf(v[q].w, v[q + 1].w));
+      if (r > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float g = filt.f[(r - 1) * 4 + q];
+          acc.x += fmaxf(prev[q].x, hm4[q].x) * g;
+          acc.y += fmaxf(prev[q].y, hm4[q].y) * g;
+          acc.z += fmaxf(prev[q].z, hm4[q].z) * g;
+          acc.w += fmaxf(prev[q].w, hm4[q].w) * g;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) prev[q] = hm4[q];
+    }
+  } else {
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int my = reflect(y0 + ky, hm);
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int mx = reflect(x0 + kx, wm);
+        const float4 a = *reinterpret_cast<const float4*>(base + ((size_t)my * w + mx) * c);
+        const float4 bq = *reinterpret_cast<const float4*>(base + ((size_t)my * w + mx + 1) * c);
+        const float4 cq4 = *reinterpret_cast<const float4*>(base + ((size_t)(my + 1) * w + mx) * c);
+        const float4 d = *reinterpret_cast<const float4*>(base + ((size_t)(my + 1) * w + mx + 1) * c);
+        const float g = filt.f[ky * 4 + kx];
+        acc.x += fmaxf(fmaxf(a.x, bq.x), fmaxf(cq4.x, d.x)) * g;
+        acc.y += fmaxf(fmaxf(a.y, bq.y), fmaxf(cq4.y, d.y)) * g;
+        acc.z += fmaxf(fmaxf(a.z, bq.z), fmaxf(cq4.z, d.z)) * g;
+        acc.w += fmaxf(fmaxf(a.w, bq.w), fmaxf(cq4.w, d.w)) * g;
+      }
+    }
+  }
+  return acc;
+}
+
 __global__ __launch_bounds__(256) void maxblur_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h,
                                                      int w, int c, int ho, int wo, BlurFilt filt) {
   const int c4 = c >> 2;
@@ -124,56 +180,30 @@ __global__ __launch_bounds__(256) void maxblur_kernel(const float* __restrict__ 
     const int oy = (int)(r % ho);
     const int b = (int)(r / ho);
     const float* base = in + (size_t)b * h * w * c + cq * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int y0 = oy * 2 - 1, x0 = ox * 2 - 1;
-    if (y0 >= 0 && y0 + 3 < hm && x0 >= 0 && x0 + 3 < wm) {
-      // interior: the 4x4 window of 2x2 maxima comes from a 5x5 input window, walked row by row
-      float4 prev[4];
-#pragma unroll
-      for (int r = 0; r < 5; ++r) {
-        const float* rp = base + ((size_t)(y0 + r) * w + x0) * c;
-        float4 v[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) v[q] = *reinterpret_cast<const float4*>(rp + (size_t)q * c);
-        float4 hm4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          hm4[q] = make_float4(fmaxf(v[q].x, v[q + 1].x), fmaxf(v[q].y, v[q + 1].y), fmaxf(v[q].z, v[q + 1].z),
-                               fmaxf(v[q].w, v[q + 1].w));
-        if (r > 0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float g = filt.f[(r - 1) * 4 + q];
-            acc.x += fmaxf(prev[q].x, hm4[q].x) * g;
-            acc.y += fmaxf(prev[q].y, hm4[q].y) * g;
-            acc.z += fmaxf(prev[q].z, hm4[q].z) * g;
-            acc.w += fmaxf(prev[q].w, hm4[q].w) * g;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) prev[q] = hm4[q];
-      }
-    } else {
-#pragma unroll
-      for (int ky = 0; ky < 4; ++ky) {
-        const int my = reflect(y0 + ky, hm);
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-          const int mx = reflect(x0 + kx, wm);
-          const float4 a = *reinterpret_cast<const float4*>(base + ((size_t)my * w + mx) * c);
-          const float4 bq = *reinterpret_cast<const float4*>(base + ((size_t)my * w + mx + 1) * c);
-          const float4 cq4 = *reinterpret_cast<const float4*>(base + ((size_t)(my + 1) * w + mx) * c);
-          const float4 d = *reinterpret_cast<const float4*>(base + ((size_t)(my + 1) * w + mx + 1) * c);
-          const float g = filt.f[ky * 4 + kx];
-          acc.x += fmaxf(fmaxf(a.x, bq.x), fmaxf(cq4.x, d.x)) * g;
-          acc.y += fmaxf(fmaxf(a.y, bq.y), fmaxf(cq4.y, d.y)) * g;
-          acc.z += fmaxf(fmaxf(a.z, bq.z), fmaxf(cq4.z, d.z)) * g;
-          acc.w += fmaxf(fmaxf(a.w, bq.w), fmaxf(cq4.w, d.w)) * g;
-        }
-      }
-    }
-    *reinterpret_cast<float4*>(out + idx * 4) = acc;
+    *reinterpret_cast<float4*>(out + idx * 4) = maxblur_one(base, oy, ox, hm, wm, w, c, filt);
   }
+}
+
+// Round 5: the same outputs with a 2-D thread -> pixel mapping.  In the linear mapping a workgroup owns 256 / c4 consecutive
+// outputs of ONE row, so the three input rows that vertically adjacent outputs share come from L2 every time (trace at 8 images:
+// 71 us for 196 MB = 2.8 TB/s).  Here a workgroup owns a th x tw block of outputs (4 x 4 at 64 channels): its (2 th + 3) x (2 tw + 3)
+// input window is read once into L1 and reused by all of them.  Same arithmetic per output (maxblur_one): bit-identical.
+__global__ __launch_bounds__(256) void maxblur_tiled_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h,
+                                                           int w, int c, int ho, int wo, int tw, int th, int tiles_x,
+                                                           int tiles_y, BlurFilt filt) {
+  const int c4 = c >> 2;
+  const int hm = h - 1, wm = w - 1;
+  const int cq = threadIdx.x % c4, pl = threadIdx.x / c4;  // channel quad, pixel of the tile
+  unsigned blk = blockIdx.x;
+  const int txb = (int)(blk % (unsigned)tiles_x);
+  blk /= (unsigned)tiles_x;
+  const int tyb = (int)(blk % (unsigned)tiles_y);
+  const int b = (int)(blk / (unsigned)tiles_y);
+  const int ox = txb * tw + pl % tw, oy = tyb * th + pl / tw;
+  if (pl >= tw * th || ox >= wo || oy >= ho) return;
+  const float* base = in + (size_t)b * h * w * c + cq * 4;
+  float* o = out + ((((size_t)b * ho + oy) * wo + ox) * c4 + cq) * 4;
+  *reinterpret_cast<float4*>(o) = maxblur_one(base, oy, ox, hm, wm, w, c, filt);
 }
 
 // ---- InstanceNorm2d (affine=False, biased variance, eps) ------------------------------------------
@@ -328,6 +358,19 @@ int dt_maxblur_f32(const float* in, float* out, const float* filt16_host, int n,
   BlurFilt f;
   for (int i = 0; i < 16; ++i) f.f[i] = filt16_host[i];
   const size_t total = (size_t)n * ho * wo * (c / 4);
+  const int c4 = c / 4;
+  static const int tiled_on = [] { const char* e = getenv("DT_MAXBLUR_TILED"); return e ? atoi(e) : 1; }();
+  if (tiled_on && c4 <= 64 && 256 % c4 == 0 && 256 / c4 >= 4) {
+    const int P = 256 / c4;                       // output pixels per workgroup
+    const int tw = P >= 16 ? 4 : 2, th = P / tw;  // 4 x 4 at 64 channels
+    const int tiles_x = (wo + tw - 1) / tw, tiles_y = (ho + th - 1) / th;
+    const long blocks = (long)n * tiles_x * tiles_y;
+    if (blocks < 2147483647L) {
+      DT_LAUNCH(maxblur_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(s), in, out, n, h, w, c, ho, wo, tw, th,
+                tiles_x, tiles_y, f);
+      return check_launch("dt_maxblur_f32");
+    }
+  }
   DT_LAUNCH(maxblur_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(s), in, out, n, h, w, c, ho, wo, f);
   return check_launch("dt_maxblur_f32");
 }
@@ -374,11 +417,13 @@ typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kStemSteps = 84;
 constexpr int kStemPH = 13, kStemPW = 22;                  // patch rows, padded row pitch (21 used)
 constexpr int kStemPatch = 3 * kStemPH * kStemPW + 2;      // + slack for the zero-weight overread
+constexpr int kStemStagePitch = 36;                        // floats per pixel of the output stage (32 channels + pad)
 
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ out, int n,
                                                           int H, int W, int Ho, int Wo, int act) {
   __shared__ float patch[2][kStemPatch];
+  __shared__ __attribute__((aligned(16))) float stage[4 * 32 * kStemStagePitch];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cb = wave & 1, slot = wave >> 1;
@@ -436,22 +481,32 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(ci * 7 + ky) * 4 + j], bv, acc, 0, 0, 0);
         }
 
-    const int oy = ty * 4 + py, ox = tx * 8 + px;
-    if (have && oy < Ho && ox < Wo) {
-      float* o = out + (((size_t)b * Ho + oy) * Wo + ox) * 64 + cb * 32 + half * 4;
+    // Epilogue through a wave-private LDS stage (round 5, as in conv1x1_mfma_body): from the C layout a lane would write four
+    // 16-byte pieces 32 bytes apart; transposed, eight consecutive lanes write the 128 contiguous bytes of one pixel's 32 channels
+    float* st = stage + wave * (32 * kStemStagePitch);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + cb * 32 + q * 8 + half * 4);
-        float4 v = make_float4(acc[q * 4 + 0] + bv.x, acc[q * 4 + 1] + bv.y, acc[q * 4 + 2] + bv.z, acc[q * 4 + 3] + bv.w);
-        if (act == DT_ACT_RELU) {
-          v.x = fmaxf(v.x, 0.f);
-          v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f);
-          v.w = fmaxf(v.w, 0.f);
-        }
-        *reinterpret_cast<float4*>(o + q * 8) = v;
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + cb * 32 + q * 8 + half * 4);
+      float4 v = make_float4(acc[q * 4 + 0] + bv.x, acc[q * 4 + 1] + bv.y, acc[q * 4 + 2] + bv.z, acc[q * 4 + 3] + bv.w);
+      if (act == DT_ACT_RELU) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+      }
+      *reinterpret_cast<float4*>(st + p * kStemStagePitch + q * 8 + half * 4) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (have) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pp = j * 8 + (lane >> 3), ch = (lane & 7) * 4;  // pixel (row j, column lane >> 3) of the 4 x 8 tile
+        const int oy = ty * 4 + j, ox = tx * 8 + (lane >> 3);
+        const float4 v = *reinterpret_cast<const float4*>(st + pp * kStemStagePitch + ch);
+        if (oy < Ho && ox < Wo) *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Wo + ox) * 64 + cb * 32 + ch) = v;
       }
     }
+    __builtin_amdgcn_wave_barrier();  // (the stage is rewritten by this wave's next tile)
   }
 }
 
