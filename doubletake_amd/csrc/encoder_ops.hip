@@ -443,6 +443,43 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
   const int base_p = (2 * py) * kStemPW + 2 * px + half;
   constexpr int kLoads = (3 * kStemPH * 21 + 127) / 128;  // 7 global loads per thread and tile
 
+  // Round 5: the patch of the NEXT tile is fetched into registers before this tile's MFMAs and written to LDS after them, so
+  // that the global-load latency (7 scalar loads per thread and tile) hides behind the 84 MFMAs instead of standing between two
+  // workgroup barriers (trace at 8 images: 157 us against 84 us of matrix time).
+  float pre[kLoads];
+  // per-thread constants of its kLoads patch elements (row, column, patch offset, image offset relative to the tile origin):
+  // computed once -- in the loop they cost two integer divisions per element and tile, on the vector ALU that the MFMAs share
+  int pr[kLoads], pcol[kLoads], pofs[kLoads];
+  long gofs[kLoads];
+#pragma unroll
+  for (int it = 0; it < kLoads; ++it) {
+    const int idx = tid2 + it * 128;
+    const int ci = idx / (kStemPH * 21), rem = idx - ci * (kStemPH * 21);
+    const int r = rem / 21, c = rem - r * 21;
+    const bool ok = idx < 3 * kStemPH * 21;
+    pr[it] = ok ? r : -100000;  // (a row that is never inside the image: the element loads nothing and is not stored)
+    pcol[it] = c;
+    pofs[it] = (ci * kStemPH + r) * kStemPW + c;
+    gofs[it] = ((long)ci * H + r) * W + c;
+  }
+  auto fetch = [&](long pair_) {
+    long t_ = pair_ * 2 + slot;
+    if (t_ >= tiles) t_ = tiles - 1;
+    const int tx_ = (int)(t_ % tiles_x);
+    const int ty_ = (int)((t_ / tiles_x) % tiles_y);
+    const int b_ = (int)(t_ / ((long)tiles_x * tiles_y));
+    const int iy0_ = ty_ * 8 - 3, ix0_ = tx_ * 16 - 3;
+    const float* origin = img + (size_t)b_ * 3 * H * W + (long)iy0_ * W + ix0_;  // (may point before the image: only dereferenced in bounds)
+#pragma unroll
+    for (int it = 0; it < kLoads; ++it) {
+      const int iy = iy0_ + pr[it], ix = ix0_ + pcol[it];
+      float v = 0.f;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = origin[gofs[it]];
+      pre[it] = v;
+    }
+  };
+  if ((long)blockIdx.x < pairs) fetch(blockIdx.x);
+
   for (long pair = blockIdx.x; pair < pairs; pair += gridDim.x) {
     long t = pair * 2 + slot;
     const bool have = t < tiles;
@@ -450,23 +487,14 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
     const int tx = (int)(t % tiles_x);
     const int ty = (int)((t / tiles_x) % tiles_y);
     const int b = (int)(t / ((long)tiles_x * tiles_y));
-    const int iy0 = ty * 8 - 3, ix0 = tx * 16 - 3;
 
     __syncthreads();  // previous tile's MFMAs are done reading the patch
 #pragma unroll
-    for (int it = 0; it < kLoads; ++it) {
-      const int idx = tid2 + it * 128;
-      if (idx < 3 * kStemPH * 21) {
-        const int ci = idx / (kStemPH * 21), rem = idx - ci * (kStemPH * 21);
-        const int r = rem / 21, c = rem - r * 21;
-        const int iy = iy0 + r, ix = ix0 + c;
-        float v = 0.f;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(((size_t)b * 3 + ci) * H + iy) * W + ix];
-        my_patch[(ci * kStemPH + r) * kStemPW + c] = v;
-      }
-    }
+    for (int it = 0; it < kLoads; ++it)
+      if (pr[it] >= 0) my_patch[pofs[it]] = pre[it];
     if (tid2 < 3 * kStemPH) my_patch[tid2 * kStemPW + 21] = 0.f;  // pad column (zero weight, must be finite)
     __syncthreads();
+    if (pair + (long)gridDim.x < pairs) fetch(pair + gridDim.x);  // in flight during the MFMAs below
 
     stem_f32x16 acc;
 #pragma unroll
