@@ -247,7 +247,8 @@ def _conv_plan(srcs, conv, act, impl, L):
         impl = "wino_split"
     if impl == "mfma":
         d.transposed = 1 if _want_transposed(L, d) else 0
-    plan = (d, C.byref(d), impl, (n, co, d.h_out, d.w_out), 2.0 * n * d.h_out * d.w_out * co * ctot * k * k)
+    # (the descriptor itself, not a byref object: ctypes structures survive copy.deepcopy / pickling of the module, references do not)
+    plan = (d, impl, (n, co, d.h_out, d.w_out), 2.0 * n * d.h_out * d.w_out * co * ctot * k * k)
     cache[key] = plan
     return plan
 
@@ -259,7 +260,8 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
     along channels in order.  Returns a channels_last tensor [n, c_out, h_out, w_out].
     """
     L = _abi.lib()
-    d, dref, impl, oshape, flops = _conv_plan(srcs, conv, act, impl, L)
+    d, impl, oshape, flops = _conv_plan(srcs, conv, act, impl, L)
+    dref = C.byref(d)
     dev = srcs[0][0].device
     nsrc = len(srcs)
     p0 = srcs[0][0].data_ptr()
@@ -430,7 +432,8 @@ def conv2d_with_heads(srcs, conv: nn.Conv2d, act, xs, heads, with_exp=False):
     chip-filling Winograd layer (otherwise, and for shapes the fused entry does not take, the two calls).  Returns
     (conv output, list of head results), bit-identical to the two calls."""
     L = _abi.lib()
-    d, dref, impl, oshape, flops = _conv_plan(srcs, conv, act, "mfma", L)
+    d, impl, oshape, flops = _conv_plan(srcs, conv, act, "mfma", L)
+    dref = C.byref(d)
     if not (HEADS_IN_CONV and HEAD_MULTI_LAUNCH and impl == "wino" and 1 <= len(xs) <= 4):
         return conv2d(srcs, conv, act=act), (head_mlp_multi(xs, heads, with_exp=with_exp) if len(xs) >= 2 else
                                               [head_mlp(x, h, with_exp=with_exp) for x, h in zip(xs, heads)])
