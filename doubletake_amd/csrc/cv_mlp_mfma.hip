@@ -802,38 +802,51 @@ __global__ __launch_bounds__(256) void mlp_plan_bounds_kernel(const unsigned* __
   auto price_upto = [&](int i) -> long { return i <= 0 ? 0L : gpre[(i - 1) >> 8] + (long)pref[i - 1]; };  // cumulative price of units [0, i)
   // cumulative price at which slot j begins: workgroup blk gets 1 / nblk of the total (remainder spread over the first ones),
   // inside it the older four waves old_share of that in equal parts, the younger four the rest
+  // Two phases, so that no thread runs more than two binary searches one after the other (each is ~16 dependent loads; the
+  // pair-compensated slots used to run five: the kernel sits on the single-stream critical path in front of the volume kernel).
+  // Phase 1: every slot's own primary boundary -- for the younger waves 5..7 of a workgroup, whose final boundary depends on their
+  // partners', the END of the workgroup's share (B8) instead; phase 2 reads the partners' phase-1 results from LDS.
   int out = 0;
+  long b0 = 0, b1 = 0, cut = 0;
+  int wv = 0;
+  bool compensated = false;
   if (!have_slot) {
-    // (threads beyond the end marker only take part in the barrier below)
+    // (threads beyond the end marker only take part in the barriers below)
   } else if (j == nslots) {
     out = bound_at(total);
   } else {
     const long blk = j / nwaves;
-    const int wv = (int)(j - blk * nwaves);
+    wv = (int)(j - blk * nwaves);
     const long share = total / nblk, rem = total - share * nblk;
-    const long b0 = blk * share + min(blk, rem), b1 = b0 + share + (blk < rem ? 1 : 0);
+    b0 = blk * share + min(blk, rem);
+    b1 = b0 + share + (blk < rem ? 1 : 0);
     if (nwaves == 8) {
-      const long cut = b0 + (((b1 - b0) * old_share_q16) >> 16);
-      if (wv <= 4 || !DT_PLAN_PAIR_ROUNDING) {
-        out = bound_at((wv < 4) ? b0 + (((cut - b0) * wv) >> 2) : cut + (((b1 - cut) * (wv - 4)) >> 2));
-      } else {
-        // Units are indivisible (a wave has ~20), so every boundary above is off its target by up to a unit and the summed price of
-        // a SIMD pair (waves w and w + 4) scattered by 1.6 % rms -- +5 % for the unluckiest of 1024 pairs, which the launch waits
-        // for.  The younger waves' boundaries therefore aim at what their OLDER partners really got: pair w should end up with a
-        // quarter of what the workgroup really holds, and the boundary is the unit edge NEAREST to that (round 4, last pass).
-        const int B0 = bound_at(b0), B4 = bound_at(cut), B8 = bound_at(b1);
-        const int Bw = bound_at(b0 + (((cut - b0) * (wv - 4)) >> 2));  // first unit of older wave wv - 4
-        const long W = price_upto(B8) - price_upto(B0), older_so_far = price_upto(Bw) - price_upto(B0);
-        const long target4 = 4 * price_upto(B4) + (long)(wv - 4) * W - 4 * older_so_far;  // 4 x the cumulative price to reach
-        int hi_b = bound_at((target4 + 3) >> 2);
-        hi_b = min(max(hi_b, B4), B8);
-        const int lo_b = max(hi_b - 1, B4);
-        out = (4 * price_upto(hi_b) - target4 <= target4 - 4 * price_upto(lo_b)) ? hi_b : lo_b;
-      }
+      cut = b0 + (((b1 - b0) * old_share_q16) >> 16);
+      compensated = DT_PLAN_PAIR_ROUNDING && wv > 4;
+      if (!compensated) out = bound_at((wv < 4) ? b0 + (((cut - b0) * wv) >> 2) : cut + (((b1 - cut) * (wv - 4)) >> 2));
+      else out = bound_at(b1);  // B8, for phase 2
     } else {
       out = bound_at(b0 + (b1 - b0) * wv / nwaves);
     }
   }
+  sout[t] = out;
+  __syncthreads();
+  if (compensated) {
+    // Units are indivisible (a wave has ~20), so every boundary above is off its target by up to a unit and the summed price of
+    // a SIMD pair (waves w and w + 4) scattered by 1.6 % rms -- +5 % for the unluckiest of 1024 pairs, which the launch waits
+    // for.  The younger waves' boundaries therefore aim at what their OLDER partners really got: pair w should end up with a
+    // quarter of what the workgroup really holds, and the boundary is the unit edge NEAREST to that (round 4, last pass).
+    // (slots 0, 4 and wv - 4 of this workgroup are threads t - wv, t - wv + 4 and t - 4: same workgroup of this kernel, 256 % 8 == 0)
+    const int B0 = sout[t - wv], B4 = sout[t - wv + 4], B8 = out;
+    const int Bw = sout[t - 4];  // first unit of older wave wv - 4
+    const long W = price_upto(B8) - price_upto(B0), older_so_far = price_upto(Bw) - price_upto(B0);
+    const long target4 = 4 * price_upto(B4) + (long)(wv - 4) * W - 4 * older_so_far;  // 4 x the cumulative price to reach
+    int hi_b = bound_at((target4 + 3) >> 2);
+    hi_b = min(max(hi_b, B4), B8);
+    const int lo_b = max(hi_b - 1, B4);
+    out = (4 * price_upto(hi_b) - target4 <= target4 - 4 * price_upto(lo_b)) ? hi_b : lo_b;
+  }
+  __syncthreads();  // (phase-1 values have been read)
   // The pair-compensated boundaries of waves 5..7 are rounded on their own and can fall before their predecessor's: the volume
   // kernel's clamp keeps coverage complete either way, but two waves would then compute (and write, identically) the same
   // units.  A running maximum over the slots of a workgroup (256 % nwaves == 0: they sit in one workgroup of this kernel)
