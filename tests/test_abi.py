@@ -44,6 +44,11 @@ def test_argument_errors_are_reported_not_launched():
 
     assert L.dt_cv_mlp_pack_floats(9, ctypes.byref(n), None, None, None) == 0 and n.value == mlp_pack.dyn_steps_total(9) * 256 == 104 * 256
     assert L.dt_cv_mlp_pack_floats(7, ctypes.byref(n), None, None, None) == 0 and n.value == 81 * 256
+    # the paired-metadata step layout is defined twice -- dt::mlp_view_step_base in the kernel, mlp_pack.view_step_base on the
+    # host -- and must agree for every view count the fused kernel takes
+    for K in range(1, 16):
+        assert L.dt_cv_mlp_pack_floats(K, ctypes.byref(n), None, None, None) == 0
+        assert n.value == mlp_pack.dyn_steps_total(K) * 256, K
     assert L.dt_conv_pack_floats(64, 64, 3) == 64 * 64 * 9
     d = _abi.ConvDesc()
     assert L.dt_conv2d_f32(ctypes.byref(d), None, None, None, None, None, None, None, None) != 0
