@@ -13,9 +13,10 @@ already resident in HBM.  Synthetic closed-form inputs, formula-initialised weig
 architecture.  With N > 1 every rank runs its own keyframe stream (keyframe-batch sharding) and
 the per-step "TSDF update" (predicted depth + K + pose of every rank) is exchanged with one RCCL
 all_gather and integrated into every rank's replica TSDF, inside the timed region.  Keyframes of this workload are
-independent (offline batches), so consecutive steps alternate between two HIP streams (--streams) and their
-latency-bound conv stacks overlap; TSDF integrations stay in frame order.  "single_stream" in the JSON line is
-the same run with every step strictly after the previous one.
+independent (offline batches), so --streams of them are in flight (default 4): the schedule is the product's own
+doubletake_amd.parallel.KeyframePipeline (lanes, in-order TSDF integration, conv plan objective) -- this script submits
+one callable per keyframe to it -- and the model part of a step is a launch program recorded at the C ABI (--launch).
+"single_stream" in the JSON line is the same run with every step strictly after the previous one.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (cv_mlp_mfma_kernel) timed live with HIP events on its stream
@@ -64,8 +65,6 @@ CONFIGS = {
 ENC_WIDTHS = {"resnet18d": [64, 64, 128, 256, 512], "efficientnet": [24, 48, 64, 160, 256]}
 CFG = dict(CONFIGS["cfg2_small"])
 DEFAULT_STREAMS = 4   # keyframes in flight (round 5: 742 frames/s at 4 against 700 at 2 and 730 at 3, profiles/r4z_streams_probe.txt)
-HW_QUEUES = "8"       # GPU_MAX_HW_QUEUES for the process: the HIP runtime's default of four hardware queues makes a fifth stream
-                      # (4 model streams + the default one) share a queue with a model stream (647 instead of 742 frames/s)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)" = "Peak FP32 (vector)"
 DOT_ISSUE_SLOTS_PER_WAVE_SAMPLE = 201  # cv_dot_lds_kernel staged path, ISA count: 121 plain + 40 packed (x2) vector instructions
 PEAK_LDS_TBPS = 256 * 256 * 2.4e9 / 1e12  # 256 CUs x 256 B/clk (ds_read_b128, same guide, LDS table) x 2.4 GHz = 157 TB/s
@@ -479,36 +478,36 @@ def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1, set_plan=None):
     res = {"entry_point": 'model("test", cur_data, src_data): matching encoder on 1+K images + volume + CVEncoder + decoder',
            "frames": frames}
     prev_cache = getattr(model, "use_feature_cache", False)
-    side = [torch.cuda.Stream(device) for _ in range(n_streams)] if n_streams > 1 else None
+    from doubletake_amd.parallel import KeyframePipeline
+
     try:
-        for ns, streams in ((1, None),) + (((n_streams, side),) if side else ()):
+        for ns in (1,) + ((n_streams,) if n_streams > 1 else ()):
             leg = {}
-            if set_plan is not None:
-                leg["conv_plan_mask"] = set_plan(ns)  # (latency plan on one stream, throughput plan with keyframes in flight)
-            for mode, cache in (("cache_off", False), ("cache_on", True)):
-                model.matching_feature_cache.clear()
-                model.use_feature_cache = cache
+            # (the product's pipeline: lanes + plan objective -- latency plan on one stream, throughput plan with keyframes in
+            #  flight; no fuser here: the leg measures the model entry point)
+            pipe = KeyframePipeline(device, in_flight=ns, shard_fuser=None, conv_plan="auto" if set_plan is not None else None)
+            try:
+                leg["conv_plan_mask"] = pipe.conv_plan_mask
+                for mode, cache in (("cache_off", False), ("cache_on", True)):
+                    model.matching_feature_cache.clear()
+                    model.use_feature_cache = cache
 
-                def run(lo, hi):
-                    for f in range(lo, hi):
-                        cur, src = data[f]
-                        cur = dict(cur, **hint)
-                        if streams is None:
-                            model("test", cur, dict(src), return_mask=True)
-                        else:
-                            with torch.cuda.stream(streams[f % len(streams)]):
-                                model("test", cur, dict(src), return_mask=True)
+                    def run(lo, hi):
+                        for f in range(lo, hi):
+                            cur, src = data[f]
+                            cur = dict(cur, **hint)
+                            pipe.step(f, lambda: model("test", cur, dict(src), return_mask=True) and None)
 
-                if streams is not None:
-                    for st in streams:
-                        st.wait_stream(torch.cuda.current_stream(device))
-                run(0, 8)
-                torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-                run(8, n)
-                torch.cuda.synchronize(device)
-                dt = time.perf_counter() - t0
-                leg[mode] = {"frames_per_s": frames / dt, "ms_per_frame": dt / frames * 1e3}
+                    run(0, 8)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    run(8, n)
+                    pipe.drain()
+                    torch.cuda.synchronize(device)
+                    dt = time.perf_counter() - t0
+                    leg[mode] = {"frames_per_s": frames / dt, "ms_per_frame": dt / frames * 1e3}
+            finally:
+                pipe.close()
             if ns == 1:
                 res["streams"] = 1
                 res.update(leg)
@@ -602,9 +601,12 @@ def main():
     ap.add_argument("--tsdf-res", type=float, default=0.04,
                     help="voxel size of the bench's TSDF volume over the 8 x 8 x 3.2 m room (0.04 = the drivers' hint volume, "
                          "0.02 = their final volume)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the model part of the step from hipGraphs (model.enable_hip_graphs; one graph set per stream) "
-                         "instead of ~50 eager launches per keyframe")
+    ap.add_argument("--launch", choices=("program", "eager", "graph"), default="program",
+                    help="how the ~50 kernels of a model step reach the GPU: 'program' (default) = a launch program recorded at "
+                         "the C ABI and re-issued by one dt_program_launch call per segment (model.enable_launch_programs; one "
+                         "program per lane); 'eager' = one entry-point call per kernel from Python; 'graph' = hipGraph replay "
+                         "(model.enable_hip_graphs; one graph set per lane)")
+    ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--input-sets", type=int, default=None,
                     help="number of distinct synthetic keyframes (features, cameras, hints, prior pyramids) resident in HBM; "
                          "step i processes set i %% N, so consecutive timed steps do not re-read the same device tensors "
@@ -614,6 +616,9 @@ def main():
                     help="with --gpus 1: still create the RCCL process group and run the per-step all_gather "
                          "(checks the N>1 code path on a single GPU)")
     args = ap.parse_args()
+    if args.graph:
+        args.launch = "graph"
+    args.graph = args.launch == "graph"
     if args.input_sets is None:
         args.input_sets = 1 if args.graph else 4
     CFG.clear()
@@ -622,8 +627,9 @@ def main():
         args.streams = DEFAULT_STREAMS if CFG["batch"] == 1 else 1
     default_cfg = args.config == "cfg2_small"
 
-    if args.streams > 3:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", HW_QUEUES)  # read when the HIP runtime initialises: before torch is imported
+    from doubletake_amd import hwqueues  # (imports nothing heavy)
+
+    hwqueues.ensure(args.streams)  # GPU_MAX_HW_QUEUES is read when the HIP runtime initialises: before torch is imported
     import torch
     import torch.distributed as dist
 
@@ -654,7 +660,7 @@ def main():
 
     from doubletake_amd import _abi
     from doubletake_amd.modules import cost_volume as cvmod
-    from doubletake_amd.parallel import KeyframeShardFuser
+    from doubletake_amd.parallel import KeyframePipeline, KeyframeShardFuser
 
     _abi.lib()
     inp, pyr, t, pyr_t = build_inputs(device, seed=1000 + rank)
@@ -672,8 +678,13 @@ def main():
             return _conv_ops.PLAN_THROUGHPUT if args.conv_plan == "throughput" else _conv_ops.PLAN_LATENCY
         return int(args.conv_plan)
 
-    if "DT_CONV_OBJ" not in os.environ:  # (an explicit environment preset wins: experiment hook)
-        _conv_ops.set_plan_objective(conv_plan_for(args.streams))
+    def make_pipeline(n_streams):
+        """The product's keyframe pipeline (doubletake_amd.parallel.KeyframePipeline) with n_streams keyframes in flight: it
+        owns the lane streams, the in-order fuse chain and the conv plan objective; this script only submits steps to it."""
+        plan = None if "DT_CONV_OBJ" in os.environ else conv_plan_for(n_streams)  # (an explicit environment preset wins: experiment hook)
+        return KeyframePipeline(device, in_flight=n_streams, shard_fuser=fuser, conv_plan=plan, model=model,
+                                launch_programs=args.launch == "program")
+
     hint = {n: t[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
     # the keyframes the steps rotate through: set 0 above plus N-1 more with their own seeds (about 9 MB each at cfg2)
     in_sets = [(t, pyr_t, hint)]
@@ -740,53 +751,38 @@ def main():
         return m.forward_from_features(sa[0], sa[1], sa[2], sa[3], sa[4], sa[5], sa[6], sa[7], return_mask=True)
 
     # --streams S: consecutive keyframes are independent in this workload (offline keyframe batches: hints and cameras
-    # are inputs), so frame i runs on HIP stream i % S and the latency-bound conv stacks of neighbouring frames overlap;
-    # only the TSDF integrations are chained (frame order) through events.
-    streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if args.streams > 1 else None
-    fuse_done = {"ev": None}
+    # are inputs), so S of them are in flight.  The schedule is the product's: KeyframePipeline runs keyframe i on lane
+    # i % S, keeps the TSDF integrations in frame order and selects the conv plan objective; this script hands it one
+    # callable per keyframe.
+    def keyframe(frame_idx, timed=False):
+        out = model_step_lane(frame_idx) if graphs is not None else model_step(frame_idx)
+        if timed:
+            hook("model_end")  # mlp_end .. model_end = lowest-cost/mask + CVEncoder + decoder + heads
+        if fuser is None:
+            return None
+        b = CFG["batch"]
+        j = [((frame_idx * world + rank) * b + i) % POOL for i in range(b)]  # global keyframe index -> camera
+        sl = slice(j[0], j[0] + 1) if b == 1 else torch.as_tensor(j, device=device)
+        return out["depth_pred_s0_b1hw"], K_pool16[sl], T_pool16[sl]
+
+    pipe = make_pipeline(args.streams)
+
+    pace_s = float(os.environ.get("DT_BENCH_PACE_MS", "0")) * 1e-3  # experiment hook: minimum host time between two submissions
+    last_submit = [0.0]
 
     def step(frame_idx, timed=False):
-        if streams is None:
-            return step_on_current(frame_idx, timed)
-        st = streams[frame_idx % len(streams)]
-        with torch.cuda.stream(st):
-            return step_on_current(frame_idx, timed)
+        if pace_s > 0:
+            while time.perf_counter() - last_submit[0] < pace_s:
+                pass
+            last_submit[0] = time.perf_counter()
+        pipe.step(frame_idx, lambda: keyframe(frame_idx, timed))
 
-    def step_on_current(frame_idx, timed=False):
-        if graphs is not None:
-            out = model_step_lane(frame_idx)  # (the event hook fires between the graph segments)
-            if timed:
-                hook("model_end")
-        else:
-            out = model_step(frame_idx)
-            if timed:
-                hook("model_end")  # mlp_end .. model_end = lowest-cost/mask + CVEncoder + decoder + heads
-        if fuser is not None:
-            b = CFG["batch"]
-            j = [((frame_idx * world + rank) * b + i) % POOL for i in range(b)]  # global keyframe index -> camera
-            sl = slice(j[0], j[0] + 1) if b == 1 else torch.as_tensor(j, device=device)
-            cur = torch.cuda.current_stream(device)
-            if streams is not None and fuse_done["ev"] is not None:
-                cur.wait_event(fuse_done["ev"])  # integrate in frame order (the running mean is order dependent)
-            fuser.exchange_and_fuse(out["depth_pred_s0_b1hw"], K_pool16[sl], T_pool16[sl])
-            if streams is not None:
-                fuse_done["ev"] = torch.cuda.Event()
-                fuse_done["ev"].record(cur)
-        return out
-
-    # one eager step on the default stream first: weight packs, per-stream scratch and allocator pools are created
-    # before the steps fan out over the streams (the pack caches also order themselves across streams: _abi.wait_ready)
-    step_on_current(0)
+    # set-up, not warm-up: every lane runs two steps once so that its launch program is recorded (or its allocator pool and
+    # per-stream library scratch exist) before the W warm-up steps -- with W < 2 x lanes a lane would otherwise meet its first
+    # hipMalloc inside the timed region (770 instead of 788 frames/s at the driver's --steps 20 --warmup 5)
+    for i in range(2 * pipe.in_flight):
+        step(i)
     torch.cuda.synchronize(device)
-    if streams is not None:
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream(device))
-        # set-up, not warm-up: every stream runs two steps once so that its allocator pool and its per-stream library scratch
-        # exist before the W warm-up steps (with W < 2 x streams a stream would otherwise meet its first hipMalloc inside the
-        # timed region: 770 instead of 788 frames/s at the driver's --steps 20 --warmup 5)
-        for i in range(2 * len(streams)):
-            step(i)
-        torch.cuda.synchronize(device)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(device)
@@ -798,12 +794,9 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i, timed=True)
     host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3  # host time to ENQUEUE a step (no wait for the GPU in the loop)
-    if fuser is not None and args.tsdf_mode == "slab":
-        # slab mode: the replicas are completed by ONE gather of the x-slabs per pass -- inside the timed region, so that the
-        # mode is charged for it (on the stream that ran the last integration)
-        last = streams[(args.warmup + args.steps - 1) % len(streams)] if streams is not None else torch.cuda.current_stream(device)
-        with torch.cuda.stream(last):
-            fuser.gather_slabs()
+    # end of the pass: slab mode completes the replicas with ONE gather of the x-slabs -- inside the timed region, so that the
+    # mode is charged for it -- and the caller's stream waits for the lanes
+    pipe.finish_pass()
     torch.cuda.synchronize(device)
     if use_dist:
         dist.barrier()
@@ -826,40 +819,33 @@ def main():
     #    from (its event bracket holds the kernel alone, as the kernel trace does).  Every rank runs it (the per-step exchange
     #    is a collective), rank 0 reports.
     def side_leg(n_streams, first_frame):
-        nonlocal streams
+        nonlocal pipe
         n_main = len(events)
-        keep = streams
-        if "DT_CONV_OBJ" not in os.environ:
-            _conv_ops.set_plan_objective(conv_plan_for(n_streams))
-        if n_streams <= 1:
-            streams = None
-        else:
-            have = list(keep or [])
-            while len(have) < n_streams:
-                have.append(torch.cuda.Stream(device))
-                have[-1].wait_stream(torch.cuda.current_stream(device))
-            streams = have[:n_streams]
-        for i in range(2 * max(1, n_streams)):
-            step(first_frame + i)
-        torch.cuda.synchronize(device)
-        if use_dist:
-            dist.barrier()
-        cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            step(first_frame + 2 * max(1, n_streams) + i, timed=True)
-        leg_issue_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        torch.cuda.synchronize(device)
-        if use_dist:
-            dist.barrier()
-        el = time.perf_counter() - t1
-        cvmod.FeatureVolumeManager._event_hook = None
+        keep = pipe
+        pipe = make_pipeline(max(1, n_streams))  # (its own lanes and plan objective; restored by close())
+        try:
+            for i in range(2 * pipe.in_flight):
+                step(first_frame + i)
+            torch.cuda.synchronize(device)
+            if use_dist:
+                dist.barrier()
+            cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step(first_frame + 2 * pipe.in_flight + i, timed=True)
+            leg_issue_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            pipe.drain()
+            torch.cuda.synchronize(device)
+            if use_dist:
+                dist.barrier()
+            el = time.perf_counter() - t1
+            cvmod.FeatureVolumeManager._event_hook = None
+            leg_plan = pipe.conv_plan_mask if pipe.conv_plan_mask is not None else int(os.environ.get("DT_CONV_OBJ", "0"))
+        finally:
+            pipe.close()
+            pipe = keep
         ev = events[n_main:]
         del events[n_main:]
-        streams = keep
-        leg_plan = int(os.environ["DT_CONV_OBJ"]) if "DT_CONV_OBJ" in os.environ else conv_plan_for(n_streams)
-        if "DT_CONV_OBJ" not in os.environ:
-            _conv_ops.set_plan_objective(conv_plan_for(args.streams))
         bb = [e for tag, e, _ in ev if tag == "mlp_begin"]
         ee = [e for tag, e, _ in ev if tag == "mlp_end"]
         mm = [e for tag, e, _ in ev if tag == "model_end"]
@@ -870,13 +856,17 @@ def main():
         return leg
 
     other_counts = []
-    if streams is not None and world == 1 and graphs is None and default_cfg and not args.no_side_legs:
+    if args.streams > 1 and world == 1 and graphs is None and default_cfg and not args.no_side_legs:
         for n_s in (2, 3, 4):
             if n_s != args.streams:
                 other_counts.append(side_leg(n_s, args.warmup + args.steps + 40 * n_s))
     single = None
-    if streams is not None:  # (--streams 1: the timed region itself is the strictly sequential run)
+    if args.streams > 1:  # (--streams 1: the timed region itself is the strictly sequential run)
         single = side_leg(1, args.warmup + 2 * args.steps + 200)
+    main_plan_mask = pipe.conv_plan_mask if pipe.conv_plan_mask is not None else int(os.environ.get("DT_CONV_OBJ", "0"))
+    pipe.close()
+    if args.launch == "program":
+        model.enable_launch_programs(False)  # (the accounting / parity / side legs below run the eager entry points)
 
     # dominant kernel: average launch duration from the HIP events recorded on its stream
     begins = [e for tag, e, _ in events if tag == "mlp_begin"]
@@ -961,12 +951,16 @@ def main():
                 "frames_per_step_per_gpu": CFG["batch"],
                 "streams": args.streams,
                 "input_sets": len(in_sets),  # distinct resident keyframes; step i processes set i % N
-                "launch": "hipGraph replay of the model step (4 segments, cut around the dominant kernel), one graph set per stream; "
-                          "eager TSDF exchange/integrate" if graphs is not None else "eager",
+                "launch": {"graph": "hipGraph replay of the model step (4 segments, cut around the dominant kernel), one graph set per lane; "
+                                    "eager TSDF exchange/integrate",
+                           "program": "launch program recorded at the C ABI (dt_program_launch: 4 segments, cut around the dominant "
+                                      "kernel and behind the volume stage), one program per lane; eager TSDF exchange/integrate",
+                           "eager": "eager (one entry-point call per kernel from Python)"}[args.launch],
+                "pipeline": "doubletake_amd.parallel.KeyframePipeline",
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 # plan objective of the conv launchers in the timed region (0 = latency, 3 = throughput: doubletake_hip.h); the
                 # single-stream leg runs the latency plan under --conv-plan auto (its own conv_plan_mask says which)
-                "conv_plan_mask": int(os.environ["DT_CONV_OBJ"]) if "DT_CONV_OBJ" in os.environ else conv_plan_for(args.streams),
+                "conv_plan_mask": main_plan_mask,
                 "parallelism": f"keyframe-shard x{world}" + ("" if args.no_fuse else
                                " + all_gather(depth,K,pose) + " + ("replica TSDF integrate" if args.tsdf_mode == "replica" else
                                "x-slab TSDF integrate + one all_gather of the slabs at the end of the timed region")),
@@ -1020,7 +1014,7 @@ def main():
                 "measured_in": "single-stream leg of this run (latency plan), HIP events from the end of the volume kernel to the end of the model"
                                if single is not None else "the timed region (one stream)",
                 "in_region_latency_ms": conv_ms, "in_region_streams": args.streams,
-                "in_region_conv_plan_mask": int(os.environ["DT_CONV_OBJ"]) if "DT_CONV_OBJ" in os.environ else conv_plan_for(args.streams),
+                "in_region_conv_plan_mask": main_plan_mask,
                 # (kept for readers of earlier rounds' lines)
                 "avg_ms_single_stream": iso_ms,
                 "frac_single_stream": conv_flops / (iso_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,

@@ -40,6 +40,7 @@ SIGNATURES = {
     "dt_last_error": (C.c_char_p, []),
     "dt_device_count": (_I, []),
     "dt_kernel_launch_count": (_L, []),
+    "dt_settings_token": (_L, []),
     "dt_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dt_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dt_cv_params_floats": (_I, [_I, _I]),
@@ -117,6 +118,14 @@ SIGNATURES = {
     "dt_mc_workspace_bytes": (_L, [_I, _I, _I]),
     "dt_mc_count": (_I, [_P, _P, _I, _I, _I, _F, C.POINTER(_I), C.POINTER(_I), _P, _P, _P]),
     "dt_mc_generate": (_I, [_P, _P, _I, _I, _I, _F, C.POINTER(_I), C.POINTER(_I), _P, _P, _P, _P, _I, _P]),
+    "dt_program_begin": (_I, [_P]),
+    "dt_program_input": (_I, [_P, _L]),
+    "dt_program_mark": (_I, []),
+    "dt_program_end": (_I, [C.POINTER(_P)]),
+    "dt_program_abort": (_I, []),
+    "dt_program_launch": (_I, [_P, _I, C.POINTER(_P), _I, _P]),
+    "dt_program_info": (_L, [_P, _I]),
+    "dt_program_free": (_I, [_P]),
     "dt_mc_raster_depth_f32": (_I, [_P, _P, _I, _I, _I, _F, C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _F, _P, _P, _I, _I,
                                     _P, _P, _P]),
 }
@@ -179,7 +188,7 @@ class _ForeignStream(C.c_void_p):
 
 
 #: entry points whose trailing void* is a data pointer, not a stream
-_NO_STREAM = frozenset({"dt_conv2d_wino_split_supported"})
+_NO_STREAM = frozenset({"dt_conv2d_wino_split_supported", "dt_program_free"})
 
 
 def _guarded(fn):

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <cstdarg>
 #include <cstdio>
+#include <tuple>
+#include <utility>
 
 #include "../../include/doubletake_hip.h"
 
@@ -24,14 +26,39 @@ inline hipStream_t to_stream(dt_stream_t s) { return reinterpret_cast<hipStream_
 // compute units of HIP's CURRENT device (cached per device id: one process may drive several GPUs); 256 if unknown
 int device_cu_count();
 
-// Every kernel launch of the library goes through DT_LAUNCH so that dt_kernel_launch_count() can report how many
-// kernels a step needed (bench.py: launches of the conv stack; cheap: one relaxed atomic add per launch).
+// Every kernel launch of the library goes through DT_LAUNCH (dt::launch) so that
+//   * dt_kernel_launch_count() can report how many kernels a step needed (bench.py: launches of the conv stack; one relaxed
+//     atomic add per launch), and
+//   * a launch program can be recorded (program.hip: dt_program_begin .. dt_program_end): while the calling thread records
+//     on the launch's stream, the kernel's address, launch geometry and a copy of its arguments -- converted to the kernel's
+//     own parameter types -- are appended to the program, and the launch still executes.  dt_program_launch then re-issues the
+//     recorded launches with one host call (hipLaunchKernel per node, none of the planning above it).
 void note_launch();
-#define DT_LAUNCH(...)                \
-  do {                                \
-    ::dt::note_launch();              \
-    hipLaunchKernelGGL(__VA_ARGS__);  \
-  } while (0)
+// process-wide settings that change which kernels / grids the launchers pick (0: dt_conv_set_plan_objective, 1:
+// dt_cv_mlp_set_cu_budget) report their value here: replay mechanisms (hipGraphs, launch programs) bake those choices in at
+// capture time and key their caches on dt_settings_token()
+void note_setting(int which, int value);
+bool recording_on(hipStream_t s);  // this thread records launches of stream s
+void record_node(const void* func, dim3 grid, dim3 block, size_t shmem, int nargs, const void* const* arg_ptrs,
+                 const size_t* arg_sizes, const size_t* arg_aligns);
+
+template <typename... P, typename... A>
+inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t shmem, hipStream_t s, A&&... a) {
+  static_assert(sizeof...(P) == sizeof...(A), "kernel launched with the wrong number of arguments");
+  note_launch();
+  if (recording_on(s)) {
+    std::tuple<P...> vals{static_cast<P>(a)...};
+    constexpr int n = (int)sizeof...(P);
+    const void* ptrs[n > 0 ? n : 1];
+    const size_t sizes[n > 0 ? n : 1] = {sizeof(P)...};
+    const size_t aligns[n > 0 ? n : 1] = {alignof(P)...};
+    int i = 0;
+    std::apply([&](const auto&... v) { ((ptrs[i++] = static_cast<const void*>(&v)), ...); }, vals);
+    record_node(reinterpret_cast<const void*>(kernel), grid, block, shmem, n, ptrs, sizes, aligns);
+  }
+  hipLaunchKernelGGL(kernel, grid, block, shmem, s, std::forward<A>(a)...);
+}
+#define DT_LAUNCH(...) ::dt::launch(__VA_ARGS__)
 
 #define DT_REQUIRE(cond, ...)            \
   do {                                   \

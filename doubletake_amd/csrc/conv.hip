@@ -1654,7 +1654,7 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
   const long blocks = (long)a.n * wt_y * wt_x * a.co_blocks;
   DT_REQUIRE(blocks < 2147483647L, "dt_conv2d_wino_f32: grid too large");
   // few output blocks (the 60x80 level and below): split K over two groups of four waves
-  static const int force_split = [] { const char* e = getenv("DT_WINO_KSPLIT"); return e ? atoi(e) : 0; }();
+  static const int force_split = [] { const char* e = getenv("DT_WINO_KSPLIT"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : 0; }();
   const int ksplit = force_split ? force_split : ((blocks < 256 && a.groups >= 8 && !(conv_obj() & 1)) ? 2 : 1);
   // cross-workgroup K split (see plan_kparts): all parts when the P-fold workgroup count still fits one round of CUs,
   // only the leftover blocks when the launch is slightly larger than the chip (300 blocks at 120x160)
@@ -1680,9 +1680,9 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
   }
   const long grid = a.kplain + (blocks - a.kplain) * a.kparts;
   if (int rc = attach_scratch(to_stream(s), &a, blocks, nullptr, 0, 4096)) return rc;
-  if (ksplit == 4)
-    DT_LAUNCH(conv_wino_kernel<4>, dim3((unsigned)grid), dim3(1024), 0, to_stream(s), a);
-  else if (ksplit == 2)
+  // (a four-way in-workgroup split -- 1024 threads, 128 registers -- was an experiment of round 3: 18 spilled VGPRs and no
+  //  faster anywhere; the instantiation is gone, DT_WINO_KSPLIT accepts 1 or 2)
+  if (ksplit == 2)
     DT_LAUNCH(conv_wino_kernel<2>, dim3((unsigned)grid), dim3(512), 0, to_stream(s), a);
   else
     DT_LAUNCH(conv_wino_kernel<1>, dim3((unsigned)grid), dim3(256), 0, to_stream(s), a);
@@ -1823,6 +1823,7 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
 
 int dt_conv_set_plan_objective(int mask) {
   g_conv_obj.store(mask < 0 ? 0 : mask, std::memory_order_relaxed);
+  note_setting(0, conv_obj());
   return conv_obj();
 }
 

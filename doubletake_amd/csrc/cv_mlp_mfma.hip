@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void cv_mlp_mfma_kernel(co
     // ---- per-pixel, plane-independent part ------------------------------------------------
     float cur8[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) cur8[j] = a.cur[((size_t)b * kF + half * 8 + j) * hw + pc];
+    for (int j = 0; j < 8; ++j) cur8[j] = a.cur[((size_t)b * kF + (lane_t >> 5) * 8 + j) * hw + pc];
     float rx, ry, rz;
     pixel_ray(p + kCvInvK, x, y, rx, ry, rz);
     // F.normalize: r / max(|r|, 1e-12)
@@ -1037,6 +1037,7 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
 
 int dt_cv_mlp_set_cu_budget(int cus) {
   g_mlp_cu_budget.store(cus > 0 ? cus : 0, std::memory_order_relaxed);
+  note_setting(1, num_cus());
   return num_cus();
 }
 

@@ -21,6 +21,7 @@ from ..modules.networks import CVEncoder, DepthDecoderPP, ResnetMatchingEncoder
 from ..modules.networks_fast import SkipDecoderRegression
 from ..utils import graphs as _graphs
 from ..utils.graphs import GraphedCallable
+from ..utils.program import RecordedCallable
 
 #: channel widths of the timm image encoders the reference uses (doubletake_model.py:121-130)
 ENCODER_WIDTHS = {"resnet18d": [64, 64, 128, 256, 512], "efficientnet": [24, 48, 64, 160, 256]}
@@ -55,8 +56,13 @@ class MatchingFeatureCache:
             from .. import _abi
 
             _abi.wait_ready(ready, feat.device)
-            if ready[0] is not None:  # still in flight on the producer stream: keep the allocator from recycling it early
-                feat.record_stream(torch.cuda.current_stream(feat.device))
+            # the entry lives in the producer stream's allocator pool; a consumer on ANOTHER stream (several keyframes in
+            # flight) must be known to the allocator whether or not the producer has finished: an eviction, a put() of the
+            # same frame id or clear() while this stream's kernels are still queued would otherwise hand the block back to
+            # the producer's pool under their reads
+            cur = torch.cuda.current_stream(feat.device)
+            if cur.cuda_stream != ready[1]:
+                feat.record_stream(cur)
         return feat
 
     def put(self, fid, feat, ready=None):
@@ -285,23 +291,64 @@ class _HotPathDepthModel(nn.Module):
                 hook = self.__dict__.pop("after_volume", None)
                 if hook is not None:
                     hook()
-            else:  # "mlp_begin" / "mlp_end": the event hook bench.py brackets the dominant kernel with
-                from ..modules.cost_volume import FeatureVolumeManager
-
-                hook = FeatureVolumeManager._event_hook
-                if hook is not None:
-                    hook(tag)
+            else:  # "mlp_begin" / "mlp_end": the event hook bench.py brackets the dominant kernel with, and the pipeline's gate
+                self._volume_hooks(tag)
 
         def cut_config():
             # which cuts the eager function would place right now: part of the graph cache key, so that a graph captured
-            # before a hook was installed is not replayed (its hook never called) once one is
+            # before a hook was installed is not replayed (its hook never called) once one is; and the process-wide
+            # switches that decide which kernels the captured launches are
             from ..modules.cost_volume import FeatureVolumeManager
 
-            return ("after_volume" in self.__dict__, FeatureVolumeManager._event_hook is not None)
+            return ("after_volume" in self.__dict__, FeatureVolumeManager._event_hook is not None or
+                    "_stage_hook" in self.cost_volume.__dict__, self._launch_config())
 
         self._graphed_forward = (GraphedCallable(self._forward_from_features_eager, between=between, cut_config=cut_config)
                                  if on else None)
         self._graphed_encoder = GraphedCallable(lambda img: self.matching_model(img)) if on and self.matching_model is not None else None
+        return self
+
+    def _volume_hooks(self, tag):
+        """What the eager volume manager calls around its kernel (cost_volume._forward_impl), for the replay mechanisms'
+        ``between`` callbacks: the pipeline's gate outside, the timing hook inside."""
+        from ..modules.cost_volume import FeatureVolumeManager
+
+        gate = self.cost_volume.__dict__.get("_stage_hook")
+        hook = FeatureVolumeManager._event_hook
+        first, second = (gate, hook) if tag == "mlp_begin" else (hook, gate)
+        if first is not None:
+            first(tag)
+        if second is not None:
+            second(tag)
+
+    def _launch_config(self):
+        cv = self.cost_volume
+        return ops.launch_config() + (getattr(cv, "precision", None), getattr(cv, "use_span_plan", None),
+                                      getattr(cv, "channels_last_output", None))
+
+    def enable_launch_programs(self, on=True):
+        """Replay ``forward_from_features`` from a launch program recorded at the C ABI (utils/program.py, csrc/program.hip):
+        the ~50 kernel launches of cost volume + CVEncoder + decoder + heads are recorded once per (input signature, stream) and
+        re-issued by ``dt_program_launch`` -- one host call per segment instead of one per kernel plus the module code
+        around it (0.8 ms -> 0.2 ms of host time per keyframe at 640x480).  Same kernels, same arguments: bit-identical to the
+        eager path.  The returned tensors are STATIC buffers of the (signature, stream) pair, overwritten by the next call
+        with that pair: consume or clone them first (``parallel.KeyframePipeline`` and the per-scan loops do).  The program is
+        cut around the volume kernel and behind the volume stage, so the event hook (bench.py) and the one-shot
+        ``after_volume`` hook (loops.matching_lookahead) work without a new recording.  Weights may change between calls
+        (programs are keyed on their versions); inputs must be dense fp32 (NHWC pyramids) -- what the eager path accepts
+        without converting."""
+        def between(tag):
+            if tag == "after_volume":
+                hook = self.__dict__.pop("after_volume", None)
+                if hook is not None:
+                    hook()
+            else:
+                self._volume_hooks(tag)
+
+        if on and getattr(self, "_recorded_forward", None) is not None:
+            return self  # (already on: keep the recorded programs)
+        self._recorded_forward = (RecordedCallable(self._forward_from_features_eager, between=between,
+                                                   cut_config=self._launch_config) if on else None)
         return self
 
     def _weights_token(self):
@@ -329,7 +376,9 @@ class _HotPathDepthModel(nn.Module):
                               cur_cam_T_src_cam, src_K, cur_invK, cv_depth_hint_dict=None, return_mask=False):
         """cur_feats: list of 5 image-prior maps (strides 2..32); matching feats at stride 4.
         Returns the reference's output dict (doubletake_model.py:410-423)."""
-        g = getattr(self, "_graphed_forward", None)
+        g = getattr(self, "_recorded_forward", None)
+        if g is None:
+            g = getattr(self, "_graphed_forward", None)
         if g is None:
             return self._forward_from_features_eager(cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
                                                      cur_cam_T_src_cam, src_K, cur_invK, cv_depth_hint_dict, return_mask)
@@ -361,9 +410,9 @@ class _HotPathDepthModel(nn.Module):
         cost_volume, lowest_cost, overall_mask = self.volume_stage(kw)
         # graph mode: the replay is split here so that the hook below runs between the halves -- only when a hook is
         # waiting at capture time (every cut is one more hipGraphLaunch per replay)
-        if "after_volume" in self.__dict__:
-            _graphs.cut("after_volume")
-        hook = None if (torch.cuda.is_current_stream_capturing() or _graphs.in_warmup()) else self.__dict__.pop("after_volume", None)
+        if "after_volume" in self.__dict__ or _graphs.recording():
+            _graphs.cut("after_volume")  # (launch programs: always -- a segment is one more C call, not a hipGraphLaunch)
+        hook = None if _graphs.building() else self.__dict__.pop("after_volume", None)
         if hook is not None:
             # one-shot: work for the caller to enqueue on ANOTHER stream behind the volume kernel (which fills every CU
             # and all of its LDS) and beside the conv stack that follows (latency-bound, most of the chip idle):

@@ -168,14 +168,31 @@ PLAN_THROUGHPUT = 11
 _WINO_MIN_BLOCKS_BY_PLAN = {False: 96, True: 48}  # (throughput plan: True)
 
 
+_PLAN_MASK = int(_os.environ.get("DT_CONV_OBJ", "0") or 0)  # (the library presets itself from the same variable)
+
+
+def current_plan_objective():
+    """The objective mask in force (what the last set_plan_objective returned; DT_CONV_OBJ before the first call)."""
+    return _PLAN_MASK
+
+
 def set_plan_objective(mask):
     """Select the plan objective (PLAN_LATENCY / PLAN_THROUGHPUT or a bit mask, see the header); returns the mask in force.
     Also moves the Winograd threshold (WINO_MIN_BLOCKS) unless DT_CONV_WINO_MIN_BLOCKS pins it."""
-    global WINO_MIN_BLOCKS
-    got = int(_abi.lib().dt_conv_set_plan_objective(int(mask)))
+    global WINO_MIN_BLOCKS, _PLAN_MASK
+    got = _PLAN_MASK = int(_abi.lib().dt_conv_set_plan_objective(int(mask)))
     if "DT_CONV_WINO_MIN_BLOCKS" not in _os.environ:
         WINO_MIN_BLOCKS = _WINO_MIN_BLOCKS_BY_PLAN[bool(got & 1)]
     return got
+
+
+def launch_config():
+    """Hashable of everything process-wide that decides WHICH kernels a conv / volume call launches and with what grid: the
+    module switches above and the library's settings token (plan objective, volume-kernel CU budget).  Replay mechanisms
+    (utils/graphs.py, utils/program.py) bake those decisions in; the model keys its captured graphs / recorded programs on
+    this, so a switch flipped afterwards leads to a new capture instead of a silent replay of the old choice."""
+    return (int(_abi.lib().dt_settings_token()), WINO_MIN_BLOCKS, CONV_PRECISION, SPLIT_MIN_BLOCKS, TRANSPOSED_TILING, PAIR_LAUNCH,
+            HEAD_MULTI_LAUNCH, HEADS_IN_CONV)
 
 
 def _dev_param(conv, name, device):
@@ -249,6 +266,8 @@ def _conv_plan(srcs, conv, act, impl, L):
         d.transposed = 1 if _want_transposed(L, d) else 0
     # (the descriptor itself, not a byref object: ctypes structures survive copy.deepcopy / pickling of the module, references do not)
     plan = (d, impl, (n, co, d.h_out, d.w_out), 2.0 * n * d.h_out * d.w_out * co * ctot * k * k)
+    if len(cache) >= 64:  # (varying input shapes: bounded; a fixed-shape loop uses one or two entries)
+        cache.clear()
     cache[key] = plan
     return plan
 
@@ -435,7 +454,7 @@ def conv2d_with_heads(srcs, conv: nn.Conv2d, act, xs, heads, with_exp=False):
     d, impl, oshape, flops = _conv_plan(srcs, conv, act, "mfma", L)
     dref = C.byref(d)
     if not (HEADS_IN_CONV and HEAD_MULTI_LAUNCH and impl == "wino" and 1 <= len(xs) <= 4):
-        return conv2d(srcs, conv, act=act), (head_mlp_multi(xs, heads, with_exp=with_exp) if len(xs) >= 2 else
+        return conv2d(srcs, conv, act=act), (head_mlp_multi(xs, heads, with_exp=with_exp) if (len(xs) >= 2 and HEAD_MULTI_LAUNCH) else
                                               [head_mlp(x, h, with_exp=with_exp) for x, h in zip(xs, heads)])
     dev = srcs[0][0].device
     nsrc = len(srcs)

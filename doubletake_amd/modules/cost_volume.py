@@ -160,6 +160,24 @@ class CostVolumeManager(nn.Module):
         return torch.gather(depth_planes_bdhw, 1, indices.unsqueeze(1)).squeeze(1)
 
     # -- shared plumbing ---------------------------------------------------------------------
+    def _per_batch(self, t, b, dev, slot):
+        """min / max depth as a dense fp32 [b] device tensor.  The reference passes [1,1,1,1] tensors for any batch size: the
+        expanded copy is kept per (tensor version, b), so a fixed-shape loop launches no torch kernel here (a launch program,
+        utils/program.py, could not replay one)."""
+        flat = t.reshape(-1)
+        if flat.numel() == b and flat.device == dev and flat.dtype == torch.float32 and flat.is_contiguous():
+            return flat
+        key = (t.data_ptr(), t._version, b, str(dev))
+        hit = self.__dict__.get(slot)
+        if hit is not None and hit[0] == key:
+            _abi.wait_ready(hit[2], dev)
+            return hit[1]
+        v = _f32c(t.to(dev)).reshape(-1)
+        if v.numel() != b:
+            v = v.expand(b).contiguous()
+        self.__dict__[slot] = (key, v, _abi.record_ready(dev))
+        return v
+
     def _setup(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
                depth_planes_bdhw):
         _require_gpu(cur_feats, "cur_feats")
@@ -177,12 +195,8 @@ class CostVolumeManager(nn.Module):
         ext = _f32c(src_extrinsics).view(b, k, 4, 4)
         poses = _f32c(src_poses).view(b, k, 4, 4)
         invK = _f32c(cur_invK).view(b, 4, 4)
-        mn = _f32c(min_depth.to(dev)).reshape(-1)
-        mx = _f32c(max_depth.to(dev)).reshape(-1)
-        if mn.numel() != b:  # the reference passes [1,1,1,1] tensors for any batch size
-            mn = mn.expand(b).contiguous()
-        if mx.numel() != b:
-            mx = mx.expand(b).contiguous()
+        mn = self._per_batch(min_depth, b, dev, "_dt_min_b")
+        mx = self._per_batch(max_depth, b, dev, "_dt_max_b")
         pf = L.dt_cv_params_floats(D, k)
         params = torch.empty(b, pf, device=dev, dtype=torch.float32)
         _abi.check(L.dt_cv_setup_f32(_abi.ptr(Ks), _abi.ptr(ext), _abi.ptr(poses), _abi.ptr(invK), _abi.ptr(mn),
@@ -407,11 +421,17 @@ class FeatureVolumeManager(CostVolumeManager):
             _abi.check(L.dt_cv_mlp_plan_f32(_abi.ptr(params), b, k, h, w, D, _abi.ptr(plan), int(plan.numel()), stream),
                        "dt_cv_mlp_plan_f32")
         hook = FeatureVolumeManager._event_hook
-        if hook is not None:
-            _graphs.cut("mlp_begin")  # (hipGraph capture: segment boundary so that the hook's events bracket the kernel on
-            #                           replay too; without a hook no cut -- every cut is one more hipGraphLaunch per replay)
-        if hook is not None and not torch.cuda.is_current_stream_capturing():
-            hook("mlp_begin")
+        if hook is not None or _graphs.recording() or "_stage_hook" in self.__dict__:
+            # replay mechanisms: segment boundary so that the hook's events bracket the kernel on replay too.  hipGraph capture:
+            # only with a hook installed (every cut is one more hipGraphLaunch per replay); launch programs: always (a segment
+            # costs one more C call, and a hook installed later then needs no new recording)
+            _graphs.cut("mlp_begin")
+        gate = self.__dict__.get("_stage_hook")  # per-instance: parallel.KeyframePipeline orders the volume kernels of its lanes
+        if not _graphs.building():
+            if gate is not None:
+                gate("mlp_begin")
+            if hook is not None:
+                hook("mlp_begin")
         if _impl == "mfma" and self.precision == "split16" and k <= self.MAX_SPLIT16_VIEWS:
             _abi.check(L.dt_cv_mlp_hint_split_f32(
                 _abi.ptr(cur), _abi.ptr(src_nhwc), _abi.ptr(params), _abi.ptr(pk["sp_w1dyn"]), _abi.ptr(pk["sp_w1pix"]),
@@ -436,10 +456,13 @@ class FeatureVolumeManager(CostVolumeManager):
                 stream), "dt_cv_mlp_hint_simple_f32")
         else:
             raise ValueError(_impl)
-        if hook is not None:
+        if hook is not None or _graphs.recording() or "_stage_hook" in self.__dict__:
             _graphs.cut("mlp_end")
-        if hook is not None and not torch.cuda.is_current_stream_capturing():
-            hook("mlp_end")
+        if not _graphs.building():
+            if hook is not None:
+                hook("mlp_end")
+            if gate is not None:
+                gate("mlp_end")
         low = self._lowest(L, stream, vol, params, nhwc, dims)
         mask = None
         if return_mask:

@@ -27,11 +27,16 @@ One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Three
   cfg5's 0.02 m final volume on 8 GPUs); slab fusion keeps it at N*b/N passes' worth of voxels, for one 2*X*Y*Z*(2+2)/N
   byte gather per rank at the end of the pass.
 * world == 1: nothing is exchanged and no packing kernel runs.
+* **keyframes in flight** (``KeyframePipeline``): on every rank the keyframe batches of a pass run on several HIP streams
+  (their latency-bound conv stacks overlap) while exchange + integration stay in batch order through an event chain;
+  ``run_sharded_pass(..., in_flight=4)`` / ``run_two_pass(..., in_flight=4)``.  bench.py's timed loop is a client of it.
 
 Payload per rank and step of the keyframe shard: b*(h*w + 32) halves (ScanNet depth-res 240x320:
 154 KB per frame) -> latency-bound; a direct all_gather is one hop on the fully connected xGMI mesh.
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import torch
@@ -210,31 +215,216 @@ class KeyframeShardFuser:
         return int(depth.shape[0])
 
 
-def run_sharded_pass(num_batches, batch_size_of, step_fn, shard_fuser: KeyframeShardFuser):
+#: keyframe batches in flight per GPU for batch-1 workloads (round 5: 742 frames/s at 4 against 700 at 2 and 730 at 3 at
+#: 640x480, profiles/r4z_streams_probe.txt); a batch of 8 already fills the chip -- use 1 there
+DEFAULT_IN_FLIGHT = 4
+
+
+class KeyframePipeline:
+    """Several independent keyframe batches in flight on one GPU -- the schedule of the headline number as a product feature.
+
+    Keyframe batches of the offline passes (reference test_offline_two_pass.py:76-126 and :300-470) do not depend on each
+    other: hints and cameras are inputs, only the TSDF accumulation is order dependent.  At batch 1 a keyframe is a chain of
+    ~50 latency-bound kernels that leaves most of the chip idle, so the pipeline runs keyframe i on HIP stream
+    ``i % in_flight`` ("lane") and the conv stacks of neighbouring keyframes overlap (602 -> 760 frames/s at 640x480 with 4
+    lanes).  The pipeline owns
+
+      * the lane streams (created once; allocator pools and per-stream library scratch warm up on their first steps),
+      * the in-order fuse chain: the exchange + TSDF integration of keyframe i is enqueued on ITS lane behind an event that
+        closes keyframe i-1's integration, so the replica sees the frames in the serial batch order (the fp16 running mean
+        and the weight clamp make integration order dependent, reference tools/tsdf.py:553-558) and -- with several ranks --
+        the per-step collectives are issued and executed in one order on every rank, one at a time,
+      * the conv plan objective for its lifetime (``conv_ops.PLAN_THROUGHPUT`` while more than one keyframe is in flight:
+        launch plans that leave room for the other lanes' workgroups; restored by ``close()``),
+      * the hardware-queue requirement: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues,
+        so a fifth stream (4 lanes + the default one) shares a queue with a lane (647 instead of 742 frames/s).  The variable
+        is read when the runtime initialises: call ``doubletake_amd.hwqueues.ensure(in_flight)`` before importing torch; the
+        constructor warns if it finds fewer queues than lanes + 1.
+
+    Cross-lane data (matching features of the HBM feature cache, packed weights) orders itself through the ready events its
+    producers attach (``_abi.record_ready`` / ``wait_ready``); nothing here synchronises the host.
+
+    ``model``: optional hot-path model; ``launch_programs=True`` switches it to recorded launch programs
+    (``enable_launch_programs``: one C call per model step instead of ~50 launches from Python; each lane records its own
+    program and owns its output buffers, which the lane's fuse consumes before the lane's next step overwrites them).
+
+    On a CPU device (gloo tests of the multi-rank logic) lanes are bookkeeping only: steps run in submission order.
+
+    Use as a context manager, or call ``close()``.  ``step(i, fn)`` runs ``fn()`` -> (depth_b1hw, K_b44, cam_T_world_b44) (or
+    None: this rank has no batch in this step) on lane i and enqueues the exchange + integration behind it; ``drain()`` makes
+    the caller's stream wait for every lane (end of a pass: before meshing, hint sampling, saving)."""
+
+    def __init__(self, device, in_flight=DEFAULT_IN_FLIGHT, shard_fuser=None, conv_plan="auto", model=None,
+                 launch_programs=False):
+        self.device = torch.device(device)
+        self.in_flight = max(1, int(in_flight))
+        self.shard_fuser = shard_fuser
+        self.cuda = self.device.type == "cuda"
+        self.streams = None
+        self._fuse_done = None
+        self._steps = 0
+        self._prev_plan = None
+        self._closed = False
+        self.model = model
+        if self.cuda and self.in_flight > 1:
+            caller = torch.cuda.current_stream(self.device)
+            self.streams = [torch.cuda.Stream(self.device) for _ in range(self.in_flight)]
+            for st in self.streams:
+                st.wait_stream(caller)
+            from . import hwqueues
+
+            hwqueues.check(self.in_flight)
+        if self.cuda and conv_plan is not None:
+            from .modules import conv_ops
+
+            if conv_plan == "auto":
+                mask = conv_ops.PLAN_THROUGHPUT if self.in_flight > 1 else conv_ops.PLAN_LATENCY
+            elif conv_plan in ("latency", "throughput"):
+                mask = conv_ops.PLAN_THROUGHPUT if conv_plan == "throughput" else conv_ops.PLAN_LATENCY
+            else:
+                mask = int(conv_plan)
+            self._prev_plan = conv_ops.current_plan_objective()
+            self.conv_plan_mask = conv_ops.set_plan_objective(mask)
+        else:
+            self.conv_plan_mask = None
+        if model is not None and launch_programs and self.cuda:
+            model.enable_launch_programs(True)
+        # volume gate (experiment switch DT_PIPE_GATE, default below): with the model step enqueued by one host call the host runs
+        # far ahead of the GPU and all lanes' chains are queued at once -- the hardware then runs the lanes' volume kernels (each
+        # needs every CU to itself) back to back and their conv stacks all together, the "phased" order that measured 3-5 %
+        # slower than staggered lanes (DESIGN 4.2 (vii)).  Eager launches staggered the lanes by accident (0.8 ms of host time
+        # per step); the gate does it on the GPU: keyframe i+1's volume kernel waits for keyframe i's
+        self._vol_done = None
+        self.gate = os.environ.get("DT_PIPE_GATE", "volume") if (self.streams is not None and model is not None) else "off"
+        if self.gate != "off" and hasattr(model, "cost_volume"):
+            model.cost_volume.__dict__["_stage_hook"] = self._gate
+
+    def _gate(self, tag):
+        cur = torch.cuda.current_stream(self.device)
+        if tag == "mlp_begin":
+            if self._vol_done is not None:
+                cur.wait_event(self._vol_done)
+        elif tag == "mlp_end":
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._vol_done = ev
+
+    # -- lanes -------------------------------------------------------------------------------------------------------
+    def lane_of(self, i):
+        return int(i) % self.in_flight
+
+    def lane(self, i):
+        """Context manager: torch's current stream is lane i's stream inside (a no-op with one lane or on the CPU)."""
+        if self.streams is None:
+            import contextlib
+
+            return contextlib.nullcontext()
+        return torch.cuda.stream(self.streams[self.lane_of(i)])
+
+    def step(self, i, fn, counts=None, rows=None):
+        """Keyframe batch i: ``fn()`` on lane i, then exchange + integrate in batch order.  Returns (fn's result, number of
+        frames integrated)."""
+        if self._closed:
+            raise RuntimeError("KeyframePipeline.step after close()")
+        with self.lane(i):
+            res = fn()
+            n = 0
+            if self.shard_fuser is not None:
+                depth, K, T = res if res is not None else (None, None, None)
+                n = self.fuse(depth, K, T, counts=counts, rows=rows)
+        self._steps += 1
+        return res, n
+
+    def fuse(self, depth, K, T, counts=None, rows=None):
+        """Exchange + integrate on the CURRENT stream (a lane), ordered behind the previous keyframe's integration."""
+        if self.streams is None:
+            return self.shard_fuser.exchange_and_fuse(depth, K, T, counts=counts, rows=rows)
+        cur = torch.cuda.current_stream(self.device)
+        if self._fuse_done is not None:
+            cur.wait_event(self._fuse_done)
+        n = self.shard_fuser.exchange_and_fuse(depth, K, T, counts=counts, rows=rows)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._fuse_done = ev
+        return n
+
+    def drain(self):
+        """The caller's current stream waits for everything enqueued on the lanes (no host synchronisation)."""
+        if self.streams is None:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            if st != cur:
+                cur.wait_stream(st)
+
+    def finish_pass(self):
+        """End of a pass: complete the replicas (slab mode: ONE gather of the x-slabs, issued on the lane that ran the last
+        integration so that it follows it), then ``drain()``.  Collective in slab mode: every rank calls it."""
+        if self.shard_fuser is not None:
+            if self.streams is not None and self._steps:
+                with torch.cuda.stream(self.streams[self.lane_of(self._steps - 1)]):
+                    if self._fuse_done is not None:
+                        torch.cuda.current_stream(self.device).wait_event(self._fuse_done)
+                    self.shard_fuser.gather_slabs()
+            else:
+                self.shard_fuser.gather_slabs()
+        self.drain()
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        self.drain()
+        if self.gate != "off" and self.model is not None and self.model.cost_volume.__dict__.get("_stage_hook") == self._gate:
+            del self.model.cost_volume.__dict__["_stage_hook"]
+        if self._prev_plan is not None:
+            from .modules import conv_ops
+
+            conv_ops.set_plan_objective(self._prev_plan)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+def run_sharded_pass(num_batches, batch_size_of, step_fn, shard_fuser: KeyframeShardFuser, in_flight=1, pipeline=None):
     """One pass over a scan's keyframe batches, sharded over the ranks (the loop of reference
     test_offline_two_pass.py:76-126 / :300-470 with the fuser call replaced by exchange + replica integrate).
 
     ``step_fn(batch_index) -> (depth_b1hw, K_b44, cam_T_world_b44)`` evaluates one batch (hint preparation + model);
     it only runs for this rank's batches.  ``batch_size_of(i)`` is the number of keyframes in batch i (all ranks know
-    the dataloader's length and batch size; the last batch may be short).  Returns the number of frames integrated
-    into the replica (= all frames of the scan, on every rank)."""
+    the dataloader's length and batch size; the last batch may be short).  ``in_flight``: keyframe batches in flight on
+    this GPU (``KeyframePipeline``; 1 = strictly one after the other, ``DEFAULT_IN_FLIGHT`` for batch-1 passes); or pass a
+    ``pipeline`` built by the caller (its shard fuser is replaced by ``shard_fuser`` for the pass).  Results are
+    bit-identical whatever the value: only the order of integration matters, and it is kept.  Returns the number of frames
+    integrated into the replica (= all frames of the scan, on every rank)."""
     world, rank = shard_fuser.world, shard_fuser.rank
     sizes = [int(batch_size_of(i)) for i in range(num_batches)]
     rows = max(sizes) if sizes else 0
     total = 0
-    for s in range((num_batches + world - 1) // world):
-        counts = [sizes[s * world + r] if s * world + r < num_batches else 0 for r in range(world)]
-        mine = s * world + rank
-        depth = K = T = None
-        if mine < num_batches:
-            depth, K, T = step_fn(mine)
-        total += shard_fuser.exchange_and_fuse(depth, K, T, counts=counts, rows=rows)
-    shard_fuser.gather_slabs()  # (slab mode: complete every replica before anything reads the volume; no-op otherwise)
+    own = pipeline is None
+    pipe = KeyframePipeline(shard_fuser.device, in_flight=in_flight, shard_fuser=shard_fuser) if own else pipeline
+    prev_fuser, pipe.shard_fuser = pipe.shard_fuser, shard_fuser
+    try:
+        for s in range((num_batches + world - 1) // world):
+            counts = [sizes[s * world + r] if s * world + r < num_batches else 0 for r in range(world)]
+            mine = s * world + rank
+            fn = (lambda i=mine: step_fn(i)) if mine < num_batches else (lambda: None)
+            _, n = pipe.step(s, fn, counts=counts, rows=rows)
+            total += n
+        pipe.finish_pass()  # (slab mode: complete every replica before anything reads the volume; then drain the lanes)
+    finally:
+        pipe.shard_fuser = prev_fuser
+        if own:
+            pipe.close()
     return total
 
 
 def run_two_pass(num_batches, batch_size_of, first_pass_fn, second_pass_fn, hint_shard_fuser, final_shard_fuser,
-                 between_passes=None, num_first_batches=None, first_batch_size_of=None):
+                 between_passes=None, num_first_batches=None, first_batch_size_of=None, in_flight=1, pipeline=None):
     """Offline two-pass over one scan (reference test_offline_two_pass.py:26-131 then :292-500).
 
     Pass 1 (``first_pass_fn``: model with empty hints) fills every rank's replica of the 0.04 m / 3 m hint TSDF
@@ -244,19 +434,37 @@ def run_two_pass(num_batches, batch_size_of, first_pass_fn, second_pass_fn, hint
     Pass 2 renders hints from that mesh, samples the hint TSDF's weights, runs the model and fuses into the final
     volume (``final_shard_fuser``, may be None when fusion is off).
 
+    ``in_flight`` / ``pipeline``: keyframe batches in flight per GPU in both passes (``KeyframePipeline``; the lanes are
+    drained between the passes, before the hint mesh is extracted).
+
     Revisit flow (reference test_revisit.py:104-260, ``loops.revisit_fns``): the first pass runs over ANOTHER scan --
     ``num_first_batches`` / ``first_batch_size_of`` describe that scan's keyframe batches (default: the same schedule)."""
-    nb1 = num_batches if num_first_batches is None else num_first_batches
-    n1 = run_sharded_pass(nb1, first_batch_size_of if first_batch_size_of is not None else batch_size_of, first_pass_fn,
-                          hint_shard_fuser)
-    state = between_passes(hint_shard_fuser.fuser) if between_passes is not None else None
-    if final_shard_fuser is None:
-        mine = shard_keyframes(num_batches, hint_shard_fuser.world, hint_shard_fuser.rank)
-        for i in mine:
-            second_pass_fn(i, state)
-        return n1, 0
-    n2 = run_sharded_pass(num_batches, batch_size_of, lambda i: second_pass_fn(i, state), final_shard_fuser)
-    return n1, n2
+    own = pipeline is None and in_flight > 1
+    pipe = KeyframePipeline(hint_shard_fuser.device, in_flight=in_flight, shard_fuser=hint_shard_fuser) if own else pipeline
+    try:
+        nb1 = num_batches if num_first_batches is None else num_first_batches
+        n1 = run_sharded_pass(nb1, first_batch_size_of if first_batch_size_of is not None else batch_size_of, first_pass_fn,
+                              hint_shard_fuser, pipeline=pipe)
+        state = between_passes(hint_shard_fuser.fuser) if between_passes is not None else None
+        if final_shard_fuser is None:
+            mine = shard_keyframes(num_batches, hint_shard_fuser.world, hint_shard_fuser.rank)
+            if pipe is None:
+                for i in mine:
+                    second_pass_fn(i, state)
+            else:
+                keep, pipe.shard_fuser = pipe.shard_fuser, None
+                try:
+                    for j, i in enumerate(mine):
+                        pipe.step(j, lambda i=i: second_pass_fn(i, state))
+                    pipe.drain()
+                finally:
+                    pipe.shard_fuser = keep
+            return n1, 0
+        n2 = run_sharded_pass(num_batches, batch_size_of, lambda i: second_pass_fn(i, state), final_shard_fuser, pipeline=pipe)
+        return n1, n2
+    finally:
+        if own:
+            pipe.close()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -46,8 +46,9 @@ def _rebuild(obj, tensors):
     return obj
 
 
-_TLS = threading.local()  # .capturing: the GraphedCallable whose capture is in progress on THIS thread (cut() talks to
-#                            it); .warming: True while its un-captured warm-up passes run
+_TLS = threading.local()  # .capturing: the GraphedCallable / RecordedCallable whose capture (recording) is in progress on THIS
+#                            thread (cut() talks to it); .warming: True while its un-captured warm-up passes run; .recording:
+#                            True while a RecordedCallable records (launches execute AND are recorded: no stream capture)
 
 
 def cut(tag=None):
@@ -58,6 +59,18 @@ def cut(tag=None):
     g = getattr(_TLS, "capturing", None)
     if g is not None:
         g._cut(tag)
+
+
+def recording():
+    """True while a RecordedCallable (utils/program.py) records the wrapped function's launches on this thread."""
+    return bool(getattr(_TLS, "recording", False))
+
+
+def building():
+    """True while the wrapped function runs for a replay mechanism rather than for its caller: hipGraph capture, launch-program
+    recording, or the warm-up passes in front of either.  Hooks that the replay's ``between`` callback will call (events,
+    one-shot work for another stream) must not fire then."""
+    return torch.cuda.is_current_stream_capturing() or recording() or in_warmup()
 
 
 def in_warmup():

@@ -42,6 +42,11 @@ int dt_device_count(void);
 /* Kernels launched by this library in this process so far (all streams, all entry points): lets a caller report the
  * launch count of a step as the difference of two reads (bench.py roofline_conv.launches). */
 int64_t dt_kernel_launch_count(void);
+/* A value that identifies the process-wide settings that change kernel selection or launch geometry (the values last given
+ * to dt_conv_set_plan_objective and dt_cv_mlp_set_cu_budget; "never set" is a value of its own).  Replay mechanisms above the
+ * ABI (captured hipGraphs, launch programs) bake those choices in; keying their caches on this token keeps a replay from
+ * silently using the old ones, and setting a value back makes the old captures valid again. */
+int64_t dt_settings_token(void);
 
 /* ---- layout helpers (boundary between torch NCHW tensors and the kernels' NHWC) ------ */
 int dt_nchw_to_nhwc_f32(const float* src, float* dst, int n, int c, int h, int w, dt_stream_t s);
@@ -132,7 +137,7 @@ int64_t dt_cv_mlp_plan_bytes(int batch, int h, int w, int num_planes);
 /* Compute-unit budget of the fused volume kernel (round 5: spatial partition of the chip).  The kernel is persistent -- one
  * workgroup per compute unit, each owning the whole unit (all of its LDS and registers) -- so with several keyframes in flight
  * it alternates with the latency-bound conv stacks of the other frames instead of running beside them.  With a budget of
- * `cus` (> 0, rounded down to a multiple of 8, at most the device's count; 0 = the whole device, the default) every later
+ * `cus` (> 0, rounded down to a multiple of 8 but never below 8, at most the device's count; 0 = the whole device, the default) every later
  * dt_cv_mlp_plan_f32 / dt_cv_mlp_hint*_f32 call launches only that many workgroups, leaving the other compute units to kernels of
  * other streams for the whole launch.  Same volume (the budget only changes how the (tile, plane) units are dealt to waves).
  * Process-wide; set it before a plan is written, and do not change it between dt_cv_mlp_plan_f32 and the planned call that
@@ -508,6 +513,43 @@ int dt_sparse_mc_count(int* dir, unsigned char* touch, int nb, float voxel_size,
 int dt_sparse_mc_generate(int* dir, unsigned char* touch, int nb, float voxel_size, int* keys, float* tsdf, float* weight,
                           int* count2, int capacity, int num_slots, float isolevel, float weight_threshold, const int* slot_offsets,
                           float* verts_v3, float* vert_weights_v, int64_t* faces_f3, int64_t* ids_v, int num_verts, dt_stream_t s);
+
+/* ---- launch programs: one host call per model step ------------------------------------------------------------------
+ * replaces: nothing the reference has as a function -- it is the host side of the call sequence of
+ * DepthModelCVHint.forward (experiment_modules/doubletake_model.py:341-349,375-423: cost volume -> CVEncoder -> depth
+ * decoder -> exp), which the reference enqueues op by op from Python.  Here the ~50 kernel launches of that sequence are
+ * recorded once while they run through the entry points above, and re-issued by dt_program_launch as plain
+ * hipLaunchKernel calls (no planning, no argument marshalling, no host-language call per launch).
+ *
+ *   dt_program_begin(s)        the calling THREAD starts recording the launches this library makes on stream s (they still
+ *                              execute; launches on other streams are neither recorded nor disturbed)
+ *   dt_program_input(p, n)     declares a device range [p, p+n) whose address differs between replays (an input tensor of the
+ *                              step); ranges must not overlap; returns the slot index (>= 0) or -1
+ *   dt_program_mark()          segment boundary at the current position; returns the index of the segment that starts here
+ *                              (segment 0 starts at dt_program_begin) or -1
+ *   dt_program_end(&prog)      stops recording; every 8-byte aligned argument word that points into an input range becomes
+ *                              a patch (slot, offset)
+ *   dt_program_abort()         stops recording and discards what was recorded (error paths)
+ *   dt_program_launch(prog, segment, inputs, num_inputs, s)
+ *                              re-issues the launches of one segment (segment = -1: all of them) on s, which must be the
+ *                              stream the program was recorded on (the library's per-stream split-K scratch is baked in).
+ *                              inputs[i] = this replay's address of slot i (same extents and layout as recorded); they are
+ *                              applied when segment <= 0, i.e. once per replay.  One replay at a time per program.
+ *   dt_program_info(prog, what) 0 launches, 1 segments, 2 patches, 3 input slots, 4 argument bytes; -1 on error
+ *   dt_program_free(prog)
+ *
+ * Everything else the recorded launches point at (intermediates, outputs, packed weights) must stay allocated, at the same
+ * addresses, until dt_program_free; process-wide settings that pick kernels or grids (dt_conv_set_plan_objective,
+ * dt_cv_mlp_set_cu_budget) are baked in at recording time. */
+typedef void* dt_program_t;
+int dt_program_begin(dt_stream_t s);
+int dt_program_input(const void* base, int64_t bytes);
+int dt_program_mark(void);
+int dt_program_end(dt_program_t* prog_out);
+int dt_program_abort(void);
+int dt_program_launch(dt_program_t prog, int segment, const void* const* inputs, int num_inputs, dt_stream_t s);
+int64_t dt_program_info(dt_program_t prog, int what);
+int dt_program_free(dt_program_t prog);
 
 #ifdef __cplusplus
 }

@@ -249,3 +249,38 @@ def test_legacy_format_hostile_pickle_never_runs_its_reduce_callable(tmp_path):
         z.writestr("archive/data.pkl", b"\x80\x02}.")
     with pytest.raises(RuntimeError, match="TorchScript"):
         mu.read_checkpoint_state_dict(ts)
+
+
+def test_hot_path_kernels_do_not_spill():
+    """the claim "no spills on the path" is checked against the ELF, not against a document.  The AMDGPU
+    metadata notes of every gfx950 code object in the built library: the dominant kernel (every instantiation of the fused
+    volume kernel the DoubleTake / SimpleRecon paths launch), the Winograd / direct / paired conv kernels, the head kernels and
+    the TSDF integrate kernel must have no spilled VGPRs and no private (scratch) segment.  (SGPR spills go to lanes of a
+    reserved VGPR, not to memory; they are listed, not forbidden.)"""
+    import elf_util
+
+    from doubletake_amd import _build
+
+    if elf_util.readelf() is None:
+        pytest.skip("llvm-readelf not available")
+    if not os.path.isfile(_build.LIB):
+        pytest.skip("library not built")
+    notes = elf_util.kernel_notes(_build.LIB)
+    assert len(notes) >= 60, len(notes)
+    on_path = ("cv_mlp_mfma_kernelILb1ELi8ELb0", "cv_mlp_mfma_kernelILb0ELi8ELb0", "cv_mlp_mfma_kernelILb1ELi4ELb0",
+               "cv_mlp_mfma_kernelILb0ELi4ELb0", "cv_mlp_mfma_kernelILb1ELi4ELb1", "cv_mlp_mfma_kernelILb0ELi4ELb1",
+               "conv_wino_kernel", "conv_wino_heads_kernel", "conv_pair_kernel", "conv_mfma_kernel", "conv_mfma_wshare_kernel",
+               "conv1x1_mfma_kernel", "head_mlp_kernel", "head_mlp_multi_kernel", "head_mlp_split_kernel", "tsdf_integrate_kernel",
+               "cv_lowest_cost_kernel", "cv_mask_kernel", "mlp_plan_cost_kernel", "mlp_plan_bounds_kernel", "stem_conv_kernel",
+               "maxblur", "instnorm")
+    seen = {tag: 0 for tag in on_path}
+    bad = []
+    for name, f in notes.items():
+        for tag in on_path:
+            if tag in name:
+                seen[tag] += 1
+                if f.get("vgpr_spill_count", 0) != 0 or f.get("private_segment_fixed_size", 0) != 0:
+                    bad.append((name, f.get("vgpr_count"), f.get("vgpr_spill_count"), f.get("private_segment_fixed_size")))
+    assert all(n > 0 for n in seen.values()), {k: v for k, v in seen.items() if v == 0}
+    assert not bad, bad
+    assert not any("conv_wino_kernelILi4E" in n for n in notes)  # (the experimental 1024-thread instantiation is gone)

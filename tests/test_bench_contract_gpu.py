@@ -43,6 +43,9 @@ def test_bench_json_contract():
     assert 7.0e10 < rc["direct_equivalent_flops_per_step"] < 8.5e10   # CVEncoder 37.0 G + SkipDecoder/heads 40.7 G
     assert 10 <= rc["launches"] <= 60 and rc["model_launches_per_step"] > rc["launches"]
     assert d["config"]["name"] == "cfg2_small"
+    # the schedule is the product's (parallel.KeyframePipeline) and the model step is one recorded launch program per lane
+    assert d["config"]["pipeline"] == "doubletake_amd.parallel.KeyframePipeline" and d["config"]["launch"].startswith("launch program")
+    assert d["host_issue_ms_per_step"] < 0.6 * d["ms_per_step"]
     # several keyframes in flight by default; the dominant kernel's figure comes from the isolated (single-stream) leg of
     # the same run and says so, the in-region bracket stays beside it
     import bench as _bench
@@ -88,19 +91,22 @@ def test_bench_graph_mode_keeps_the_roofline_bracket():
     assert len(lines) == 1 and "NaN" not in lines[0], lines
     d = json.loads(lines[0])
     assert d["config"]["launch"].startswith("hipGraph") and d["config"]["input_sets"] == 1
+    assert d["config"]["pipeline"] == "doubletake_amd.parallel.KeyframePipeline"
     assert 0.3 < d["roofline"]["frac"] < 1.0 and 0.3 < d["roofline"]["avg_launch_ms"] < 2.0
     assert d["other_stream_counts"] is None and "other_stream_counts" in d["null_because"]  # (side legs skipped)
 
 
 def test_multi_stream_frame_pipelining_is_bit_identical():
-    """bench.py --streams S (default 4) runs consecutive keyframes round-robin on S HIP streams with only the TSDF
-    integrations chained by events.  Same frames, same order: depth maps and the fused volume must not change by a bit,
-    at 2, 3 and 4 keyframes in flight."""
+    """parallel.KeyframePipeline (the schedule bench.py's timed loop submits its steps to): consecutive keyframes round-robin
+    on S lanes with only the TSDF integrations chained by events.  Same frames, same order: depth maps and the fused volume
+    must not change by a bit at 2, 3 and 4 keyframes in flight -- with eager launches and with one recorded launch program
+    per lane (model.enable_launch_programs)."""
     import numpy as np
     import torch
 
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import gpu_util as gu
+    from doubletake_amd import parallel
     from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
     from doubletake_amd.tools.fusers_helper import OurFuser
     from doubletake_amd.utils import synthetic as syn
@@ -117,37 +123,47 @@ def test_multi_stream_frame_pipelining_is_bit_identical():
     frames = []
     for f in range(9):
         t = gu.to_dev(syn.volume_inputs(1, k, h, w, 16, 30 + f))
-        pyr = [torch.from_numpy(p).to(dev) for p in syn.prior_pyramid(1, [64, 64, 128, 256, 512], 2 * h, 2 * w, 40 + f)]
+        pyr = [torch.from_numpy(p).to(dev).contiguous(memory_format=torch.channels_last)
+               for p in syn.prior_pyramid(1, [64, 64, 128, 256, 512], 2 * h, 2 * w, 40 + f)]
         frames.append((t, pyr))
 
-    def run(nstreams):
+    def run(in_flight, programs):
         fuser = OurFuser(None, 0.04, 3.0, bounds=bd)
-        streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream(dev))
-        done, outs = None, []
-        for f, (t, pyr) in enumerate(frames):
-            with torch.cuda.stream(streams[f % nstreams]):
-                out = model.forward_from_features(pyr, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"],
-                                                  t["src_Ks"], t["cur_invK"], gu.hint_dict(t), return_mask=True)
-                cur = torch.cuda.current_stream(dev)
-                if done is not None:
-                    cur.wait_event(done)
-                fuser.fuse_frames(out["depth_pred_s0_b1hw"].clamp(0.8, 2.0), Kt[f:f + 1], Tt[f:f + 1], None)
-                done = torch.cuda.Event()
-                done.record(cur)
-                outs.append(out["depth_pred_s0_b1hw"])
-        torch.cuda.synchronize(dev)
-        t = fuser.tsdf_fuser_pred.tsdf
-        return [o.clone() for o in outs], t.tsdf_values.clone(), t.tsdf_weights.clone()
+        sf = parallel.KeyframeShardFuser(dev, 1, 0, (2 * h, 2 * w), fuser=fuser)
+        outs = []
 
-    d1, v1, w1 = run(1)
+        def keyframe(f):
+            t, pyr = frames[f]
+            out = model.forward_from_features(pyr, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"],
+                                              t["src_Ks"], t["cur_invK"], gu.hint_dict(t), return_mask=True)
+            outs.append(out["depth_pred_s0_b1hw"].clone())  # (program mode: the lane's output buffer is overwritten 'in_flight' steps later)
+            return out["depth_pred_s0_b1hw"].clamp(0.8, 2.0), Kt[f:f + 1], Tt[f:f + 1]
+
+        # (conv_plan: the same launch plans in every run -- the default "auto" selects the throughput plan with keyframes in
+        #  flight, whose K splits sum in another fp32 order: a few 1e-6, tests/test_networks_gpu.py)
+        with parallel.KeyframePipeline(dev, in_flight=in_flight, shard_fuser=sf, model=model, launch_programs=programs,
+                                       conv_plan="latency") as pipe:
+            assert (pipe.streams is None) == (in_flight == 1)
+            for f in range(len(frames)):
+                pipe.step(f, lambda f=f: keyframe(f))
+            pipe.finish_pass()
+        torch.cuda.synchronize(dev)
+        if programs:
+            info = model._recorded_forward.info()
+            assert len(info) == in_flight and all(e["launches"] >= 20 and e["segments"] == 4 and e["patches"] >= 10 for e in info), info
+        model.enable_launch_programs(False)
+        t = fuser.tsdf_fuser_pred.tsdf
+        return outs, t.tsdf_values.clone(), t.tsdf_weights.clone()
+
+    d1, v1, w1 = run(1, False)
     assert (w1 > 0).sum().item() > 1000
-    for nstreams in (2, 3, 4):
-        d2, v2, w2 = run(nstreams)
-        for a, b in zip(d1, d2):
-            assert torch.equal(a, b), nstreams
-        assert torch.equal(v1.view(torch.int16), v2.view(torch.int16)) and torch.equal(w1.view(torch.int16), w2.view(torch.int16)), nstreams
+    for programs in (False, True):
+        for in_flight in ((2, 3, 4) if not programs else (1, 4)):
+            d2, v2, w2 = run(in_flight, programs)
+            for a, b in zip(d1, d2):
+                assert torch.equal(a, b), (in_flight, programs)
+            assert torch.equal(v1.view(torch.int16), v2.view(torch.int16)) and torch.equal(w1.view(torch.int16), w2.view(torch.int16)), \
+                (in_flight, programs)
 
 
 def test_forced_collective_line_carries_every_key_of_the_plain_line():
