@@ -434,7 +434,7 @@ def encoder_flops_per_image(H, W, c_out=16):
     return 2.0 * (147 * 64 * p2 + 4 * 576 * 64 * p4 + 64 * 128 * p4 + 1152 * c_out * p4)
 
 
-def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1, set_plan=None):
+def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1, set_plan=None, launch_programs=False):
     """Frames/s of the reference entry point ``model("test", cur_data, src_data)`` INCLUDING the HIP matching encoder
     (ResnetMatchingEncoder, reference modules/networks.py:138-189) on the 1 + K images of every keyframe -- the step just
     before the volume that the headline (forward_from_features) leaves outside.  Image-prior encoder: out of scope (a
@@ -476,7 +476,7 @@ def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1, set_plan=None):
         data.append((cur, src))
     hint = {nm: t[nm] for nm in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
     res = {"entry_point": 'model("test", cur_data, src_data): matching encoder on 1+K images + volume + CVEncoder + decoder',
-           "frames": frames}
+           "frames": frames, "launch": "program" if launch_programs else "eager"}
     prev_cache = getattr(model, "use_feature_cache", False)
     from doubletake_amd.parallel import KeyframePipeline
 
@@ -485,7 +485,8 @@ def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1, set_plan=None):
             leg = {}
             # (the product's pipeline: lanes + plan objective -- latency plan on one stream, throughput plan with keyframes in
             #  flight; no fuser here: the leg measures the model entry point)
-            pipe = KeyframePipeline(device, in_flight=ns, shard_fuser=None, conv_plan="auto" if set_plan is not None else None)
+            pipe = KeyframePipeline(device, in_flight=ns, shard_fuser=None, conv_plan="auto" if set_plan is not None else None,
+                                    model=model, launch_programs=launch_programs)
             try:
                 leg["conv_plan_mask"] = pipe.conv_plan_mask
                 for mode, cache in (("cache_off", False), ("cache_on", True)):
@@ -513,7 +514,10 @@ def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1, set_plan=None):
                 res.update(leg)
             else:
                 res[f"streams_{ns}"] = leg
-        # the matching encoder alone: 1 + K images in one pass (cache off) and one image (cache on / incremental mode)
+        # the matching encoder alone: 1 + K images in one pass (cache off) and one image (cache on / incremental mode); eager
+        # launches (the launch counter counts entry-point launches)
+        if launch_programs:
+            model.enable_launch_programs(False)
         if set_plan is not None:
             set_plan(1)
         L = _abi.lib()
@@ -531,6 +535,8 @@ def end_to_end(device, t, pyr_t, model, frames=40, n_streams=1, set_plan=None):
                         "achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
         enc["achieved"], enc["frac"] = enc["batched_1_plus_K"]["achieved"], enc["batched_1_plus_K"]["frac"]
     finally:
+        if launch_programs:
+            model.enable_launch_programs(False)
         model.use_feature_cache = prev_cache
         model.encoder = prev_enc
         model.matching_feature_cache.clear()
@@ -790,10 +796,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
+    wait0 = pipe.host_wait_s
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, timed=True)
-    host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3  # host time to ENQUEUE a step (no wait for the GPU in the loop)
+    # host time to ENQUEUE a step, net of the time the pipeline's back-pressure kept the host blocked on the GPU (max_lead)
+    host_wait_ms = (pipe.host_wait_s - wait0) / args.steps * 1e3
+    host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3 - host_wait_ms
     # end of the pass: slab mode completes the replicas with ONE gather of the x-slabs -- inside the timed region, so that the
     # mode is charged for it -- and the caller's stream waits for the lanes
     pipe.finish_pass()
@@ -830,10 +839,11 @@ def main():
             if use_dist:
                 dist.barrier()
             cvmod.FeatureVolumeManager._event_hook = staticmethod(hook)
+            w1 = pipe.host_wait_s
             t1 = time.perf_counter()
             for i in range(args.steps):
                 step(first_frame + 2 * pipe.in_flight + i, timed=True)
-            leg_issue_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            leg_issue_ms = (time.perf_counter() - t1 - (pipe.host_wait_s - w1)) / args.steps * 1e3
             pipe.drain()
             torch.cuda.synchronize(device)
             if use_dist:
@@ -863,6 +873,7 @@ def main():
     single = None
     if args.streams > 1:  # (--streams 1: the timed region itself is the strictly sequential run)
         single = side_leg(1, args.warmup + 2 * args.steps + 200)
+    main_max_lead = pipe.max_lead
     main_plan_mask = pipe.conv_plan_mask if pipe.conv_plan_mask is not None else int(os.environ.get("DT_CONV_OBJ", "0"))
     pipe.close()
     if args.launch == "program":
@@ -935,6 +946,9 @@ def main():
             # host time to enqueue one step (Python + ctypes + HIP launch calls of ~50 kernels; the loop never waits for the GPU):
             # while it stays below ms_per_step the run is GPU-bound
             "host_issue_ms_per_step": host_issue_ms,
+            # of the wall time of the loop, what the host spent blocked in the pipeline's back-pressure (it may be at most
+            # config.max_lead steps ahead of the GPU): waiting, not work
+            "host_wait_ms_per_step": host_wait_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -957,6 +971,7 @@ def main():
                                       "kernel and behind the volume stage), one program per lane; eager TSDF exchange/integrate",
                            "eager": "eager (one entry-point call per kernel from Python)"}[args.launch],
                 "pipeline": "doubletake_amd.parallel.KeyframePipeline",
+                "max_lead": main_max_lead,  # steps the host may run ahead of the GPU (0 = unbounded)
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 # plan objective of the conv launchers in the timed region (0 = latency, 3 = throughput: doubletake_hip.h); the
                 # single-stream leg runs the latency plan under --conv-plan auto (its own conv_plan_mask says which)
@@ -1036,7 +1051,7 @@ def main():
             if not args.no_side_legs:
                 result["roofline_tsdf"] = tsdf_roofline(device)
                 result["end_to_end"], result["roofline_encoder"] = end_to_end(
-                    device, t, pyr_t, model, n_streams=args.streams,
+                    device, t, pyr_t, model, n_streams=args.streams, launch_programs=args.launch == "program",
                     set_plan=None if "DT_CONV_OBJ" in os.environ else (lambda ns: _conv_ops.set_plan_objective(conv_plan_for(ns))))
         if not default_cfg:
             result["cpu_baseline"] = None  # the CPU leg is defined on the default workload

@@ -349,6 +349,10 @@ class _HotPathDepthModel(nn.Module):
             return self  # (already on: keep the recorded programs)
         self._recorded_forward = (RecordedCallable(self._forward_from_features_eager, between=between,
                                                    cut_config=self._launch_config) if on else None)
+        # the single-image matching-encoder pass of the feature cache (the incremental loop encodes exactly one new keyframe
+        # per frame: 14 launches)
+        self._recorded_encoder = (RecordedCallable(lambda img: self.matching_model(img), cut_config=ops.launch_config)
+                                  if on and self.matching_model is not None else None)
         return self
 
     def _weights_token(self):
@@ -362,7 +366,9 @@ class _HotPathDepthModel(nn.Module):
     def _encode(self, images_n3hw):
         """Matching encoder pass; single images replay a captured graph when graphs are on (the incremental loop encodes
         exactly one new keyframe per frame)."""
-        g = getattr(self, "_graphed_encoder", None)
+        g = getattr(self, "_recorded_encoder", None)
+        if g is None:
+            g = getattr(self, "_graphed_encoder", None)
         if g is not None and images_n3hw.shape[0] == 1:
             token = tuple((p.data_ptr(), p._version) for p in self.matching_model.parameters())
             if getattr(self, "_encoder_token", token) != token:

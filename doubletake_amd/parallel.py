@@ -37,6 +37,7 @@ Payload per rank and step of the keyframe shard: b*(h*w + 32) halves (ScanNet de
 from __future__ import annotations
 
 import os
+import time
 
 import numpy as np
 import torch
@@ -218,6 +219,8 @@ class KeyframeShardFuser:
 #: keyframe batches in flight per GPU for batch-1 workloads (round 5: 742 frames/s at 4 against 700 at 2 and 730 at 3 at
 #: 640x480, profiles/r4z_streams_probe.txt); a batch of 8 already fills the chip -- use 1 there
 DEFAULT_IN_FLIGHT = 4
+#: in_flight -> how many steps the host may run ahead of the GPU (KeyframePipeline max_lead="auto"); others: in_flight + 1
+DEFAULT_MAX_LEAD = {1: 2}
 
 
 class KeyframePipeline:
@@ -255,9 +258,20 @@ class KeyframePipeline:
     the caller's stream wait for every lane (end of a pass: before meshing, hint sampling, saving)."""
 
     def __init__(self, device, in_flight=DEFAULT_IN_FLIGHT, shard_fuser=None, conv_plan="auto", model=None,
-                 launch_programs=False):
+                 launch_programs=False, max_lead="auto"):
         self.device = torch.device(device)
         self.in_flight = max(1, int(in_flight))
+        # back-pressure: the host may be at most `max_lead` submitted-but-unfinished steps ahead of the GPU (it blocks on the
+        # completion event of step i - max_lead before submitting step i).  Bounds the queued work (and the latency of
+        # everything queued behind it), and -- measured, profiles/r6f_lead_probe.txt -- the GPU itself is faster when a lane's
+        # next step is not already waiting behind the running one: with the model step enqueued by one C call the host
+        # otherwise runs dozens of steps ahead.  "auto": DT_PIPE_LEAD or the default below; None / 0: unbounded.
+        if max_lead == "auto":
+            env = os.environ.get("DT_PIPE_LEAD")
+            max_lead = int(env) if env else DEFAULT_MAX_LEAD.get(self.in_flight, self.in_flight + 1)
+        self.max_lead = int(max_lead) if max_lead else 0
+        self._pending = []
+        self.host_wait_s = 0.0
         self.shard_fuser = shard_fuser
         self.cuda = self.device.type == "cuda"
         self.streams = None
@@ -289,13 +303,12 @@ class KeyframePipeline:
             self.conv_plan_mask = None
         if model is not None and launch_programs and self.cuda:
             model.enable_launch_programs(True)
-        # volume gate (experiment switch DT_PIPE_GATE, default below): with the model step enqueued by one host call the host runs
-        # far ahead of the GPU and all lanes' chains are queued at once -- the hardware then runs the lanes' volume kernels (each
-        # needs every CU to itself) back to back and their conv stacks all together, the "phased" order that measured 3-5 %
-        # slower than staggered lanes.  Eager launches staggered the lanes by accident (0.8 ms of host time
-        # per step); the gate does it on the GPU: keyframe i+1's volume kernel waits for keyframe i's
+        # volume gate (experiment switch DT_PIPE_GATE=volume; default off): keyframe i+1's volume kernel waits for keyframe i's.
+        # Built to stagger the lanes on the GPU once the host no longer does it by being slow; measured no better than the
+        # hardware's own interleaving (profiles/r6d_gate_probe3.txt: 755 vs 761 frames/s at 3 lanes) -- what does help is
+        # max_lead above
         self._vol_done = None
-        self.gate = os.environ.get("DT_PIPE_GATE", "volume") if (self.streams is not None and model is not None) else "off"
+        self.gate = os.environ.get("DT_PIPE_GATE", "off") if (self.streams is not None and model is not None) else "off"
         if self.gate != "off" and hasattr(model, "cost_volume"):
             model.cost_volume.__dict__["_stage_hook"] = self._gate
 
@@ -326,12 +339,22 @@ class KeyframePipeline:
         frames integrated)."""
         if self._closed:
             raise RuntimeError("KeyframePipeline.step after close()")
+        if self.cuda and self.max_lead and len(self._pending) >= self.max_lead:
+            t0 = time.perf_counter()
+            self._pending.pop(0).synchronize()
+            self.host_wait_s += time.perf_counter() - t0  # (blocked on the GPU, not issuing: bench.py subtracts it)
         with self.lane(i):
             res = fn()
             n = 0
             if self.shard_fuser is not None:
                 depth, K, T = res if res is not None else (None, None, None)
                 n = self.fuse(depth, K, T, counts=counts, rows=rows)
+            if self.cuda and self.max_lead:
+                done = self._fuse_done if (self.shard_fuser is not None and self.streams is not None) else None
+                if done is None:
+                    done = torch.cuda.Event()
+                    done.record(torch.cuda.current_stream(self.device))
+                self._pending.append(done)
         self._steps += 1
         return res, n
 

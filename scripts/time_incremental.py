@@ -7,6 +7,7 @@ sampling -> matching encoder (new keyframe only; sources from the HBM feature ca
 Modes:  serial     feature cache, everything on one stream, eager launches (round 2's figure)
         lookahead  frame t+1's keyframe is encoded on a side stream while frame t runs (loops.matching_lookahead)
         graphs     the model part and the single-image encoder pass replayed from hipGraphs (model.enable_hip_graphs)
+        programs   the same two replayed from launch programs recorded at the C ABI (model.enable_launch_programs)
 Reported: wall-clock ms/frame over the scan (no host synchronisation inside the loop) and the FrameTimer's per-frame
 hint_time / model_time (HIP events; model_time includes the matching encoder when it is not hidden)."""
 import json
@@ -84,11 +85,12 @@ def main():
         return out
 
     res = {"config": cfg_name, "image": [H, W]}
-    modes = os.environ.get("DT_MODES", "serial,lookahead,graphs,graphs+lookahead,serial,graphs+lookahead").split(",")
+    modes = os.environ.get("DT_MODES", "serial,lookahead,graphs,programs,programs+lookahead,serial,programs,programs+lookahead").split(",")
     for mode in modes:
         model.matching_feature_cache.clear()
         model.use_feature_cache = True
         model.enable_hip_graphs("graphs" in mode)
+        model.enable_launch_programs("programs" in mode)
         fuser = OurFuser(None, 0.04, 3.0, bounds=bd)
         timer = loops.FrameTimer()
         warm = 8

@@ -484,3 +484,65 @@ def test_gather_variable_single_process():
     buf = par.pack_tsdf(torch.ones(8, 8, 8).half(), torch.zeros(8, 8, 8).half(), [1.5, -2.25, 3.0], 0.04, 7)
     d = par.unpack_tsdf(buf)
     assert d["scene_index"] == 7 and d["tsdf_values"].shape == (8, 8, 8) and float(d["tsdf_values"].sum()) == 512.0
+
+
+# ---- keyframes in flight (parallel.KeyframePipeline) on two ranks -------------------------------------------------------
+def _pipeline_worker(rank, world, port, out_dir):
+    """run_two_pass(..., in_flight=4) on two ranks.  On the CPU the lanes are bookkeeping (no streams), which
+    is exactly the part that must be rank independent: which lane a step gets, in which order the collectives are issued, in
+    which order the gathered frames are integrated.  The spy records every collective; the replicas are integrated with the
+    numpy TSDF oracle so that their bits can be compared with a serial, single-rank, in_flight=1 run."""
+    _init(rank, world, port)
+    calls = []
+    real = dist.all_gather_into_tensor
+
+    def spy(out, inp, *a, **kw):
+        calls.append((tuple(out.shape), tuple(inp.shape), str(inp.dtype)))
+        return real(out, inp, *a, **kw)
+
+    par.dist.all_gather_into_tensor = spy
+    hint, final = _OracleFuser(0.08), _OracleFuser(0.04)
+    sf_hint = par.KeyframeShardFuser(torch.device("cpu"), world, rank, (H, W), fuser=hint)
+    sf_final = par.KeyframeShardFuser(torch.device("cpu"), world, rank, (H, W), fuser=final)
+    lanes = []
+    pipe = par.KeyframePipeline(torch.device("cpu"), in_flight=4, shard_fuser=sf_hint)
+    step0 = pipe.step
+
+    def step_spy(i, fn, **kw):
+        lanes.append((i, pipe.lane_of(i)))
+        return step0(i, fn, **kw)
+
+    pipe.step = step_spy
+    second = lambda i, state: tuple(t * 1.02 if j == 0 else t for j, t in enumerate(_batch(i)))
+    n1, n2 = par.run_two_pass(NB, lambda i: SIZES[i], _batch, second, sf_hint, sf_final, between_passes=lambda f: "mesh",
+                              pipeline=pipe)
+    pipe.close()
+    par.dist.all_gather_into_tensor = real
+    assert (n1, n2) == (sum(SIZES), sum(SIZES))
+    arrays = lambda f: [f.vol.values.copy(), f.vol.weights.copy()]
+    torch.save({"calls": calls, "lanes": lanes, "hint": arrays(hint), "final": arrays(final)}, os.path.join(out_dir, f"pl{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_pass_with_four_keyframes_in_flight_on_two_ranks(tmp_path):
+    world = 2
+    _spawn(_pipeline_worker, world, str(tmp_path))
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"pl{r}.pt"), weights_only=False) for r in range(world))
+    steps = (NB + world - 1) // world
+    # the same collectives, in the same order, on both ranks: one per step and pass
+    assert r0["calls"] == r1["calls"] and len(r0["calls"]) == 2 * steps
+    # lanes are dealt round-robin by STEP index -- identical on both ranks, restarting with every pass
+    assert r0["lanes"] == r1["lanes"] == [(s, s % 4) for s in range(steps)] * 2
+    # serial reference: one rank, one keyframe at a time
+    hint, final = _OracleFuser(0.08), _OracleFuser(0.04)
+    # (a single rank exchanges nothing, so nothing casts: apply the casts of OurFuser.fuse_frames / pack_update here)
+    half = lambda f: (lambda d, K, T: f.fuse_frames(d.half(), K.half(), T.half()))
+    sh = par.KeyframeShardFuser(torch.device("cpu"), 1, 0, (H, W), fuser=hint, fuse_fn=half(hint))
+    sfin = par.KeyframeShardFuser(torch.device("cpu"), 1, 0, (H, W), fuser=final, fuse_fn=half(final))
+    second = lambda i, state: tuple(t * 1.02 if j == 0 else t for j, t in enumerate(_batch(i)))
+    par.run_two_pass(NB, lambda i: SIZES[i], _batch, second, sh, sfin, between_passes=lambda f: "mesh", in_flight=1)
+    assert hint.vol.weights.sum() > 0 and final.vol.weights.sum() > 0
+    for key, ref in (("hint", [hint.vol.values, hint.vol.weights]), ("final", [final.vol.values, final.vol.weights])):
+        for a0, a1, want in zip(r0[key], r1[key], ref):
+            np.testing.assert_array_equal(np.asarray(a0).view(np.uint16), np.asarray(want).view(np.uint16))
+            np.testing.assert_array_equal(np.asarray(a1).view(np.uint16), np.asarray(want).view(np.uint16))
