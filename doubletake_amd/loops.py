@@ -237,7 +237,9 @@ def hints_from_mesh(mesh, hint_fuser, renderer, cur_data, render_hw, hint_world_
 
 def two_pass_fns(model_fn, load_batch, render_hw, fuse_size=None, mask_pred_depth=False, on_frame=None,
                  load_first_pass_batch=None, hint_world_T_world_144=None, timer: FrameTimer | None = None):
-    """(first_pass_fn, between_passes, second_pass_fn) for ``parallel.run_two_pass``.
+    """(first_pass_fn, between_passes, second_pass_fn) for ``parallel.run_two_pass`` (``in_flight=4`` there runs the keyframe
+    batches of both passes through ``parallel.KeyframePipeline``; with ``model.enable_launch_programs()`` the outputs of
+    ``model_fn`` are lane-static buffers, which the step functions below consume before they return).
 
     ``load_batch(i) -> (cur_data, src_data)`` fetches keyframe batch i onto this rank's GPU (only called for the
     rank's own batches).  Second-pass hints: ``hints_from_mesh``.  ``load_first_pass_batch`` / ``hint_world_T_world_144``
@@ -246,11 +248,21 @@ def two_pass_fns(model_fn, load_batch, render_hw, fuse_size=None, mask_pred_dept
     H2, W2 = render_hw
     load_first = load_first_pass_batch if load_first_pass_batch is not None else load_batch
 
+    empty = {}  # (b, device) -> the pass's empty hint maps: constants the model only reads, built once, not per batch
+
     @torch.no_grad()
     def first(i):
         cur_data, src_data = load_first(i)
         b = cur_data["cam_T_world_b44"].shape[0]
-        empty_hint(cur_data, torch.zeros(b, 1, H2, W2, device=cur_data["cam_T_world_b44"].device, dtype=torch.float32))
+        dev = cur_data["cam_T_world_b44"].device
+        maps = empty.get((b, dev))
+        if maps is None:
+            maps = {}
+            empty_hint(maps, torch.zeros(b, 1, H2, W2, device=dev, dtype=torch.float32))
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()  # (read from every lane of a KeyframePipeline afterwards)
+            empty[(b, dev)] = maps
+        cur_data.update(maps)
         out = model_fn(cur_data, src_data)
         return _depth_for_fusion(out, fuse_size, mask_pred_depth, per_view_mask=False), cur_data["K_full_depth_b44"], \
             cur_data["cam_T_world_b44"]

@@ -223,7 +223,9 @@ def _up(x):
 
 
 @torch.no_grad()
-def depth_decoder_pp(input_features, p):
+def depth_decoder_pp(input_features, p, nodes=None):
+    """nodes: optional dict that receives every UNet++ node output X_ij under its ModuleDict name ``in_conv_{i}{j}`` (what a
+    forward hook on the reference's ``convs[name]`` sees)."""
     prev = list(input_features)
     outputs, depth = [], {}
     for j in range(1, 5):
@@ -235,6 +237,8 @@ def depth_decoder_pp(input_features, p):
             q = _sub(p, f"convs.in_conv_{i}{j}.")
             out = basic_block(basic_block(torch.cat(ins, 1), _sub(q, "0.")), _sub(q, "conv_0."))
             outputs.append(out)
+            if nodes is not None:
+                nodes[f"in_conv_{i}{j}"] = out
             hp = _sub(p, f"convs.output_{i}.")
             y = basic_block(out, _sub(hp, "0.")) if i != 0 else out
             depth[f"log_depth_pred_s{i}_b1hw"] = _conv(y, hp, "1")

@@ -272,3 +272,85 @@ def test_cfg2_small_whole_tensors_vs_torch_cpu_oracle():
         ld = dec[f"log_depth_pred_s{i}_b1hw"]
         assert float((out[f"log_depth_pred_s{i}_b1hw"].cpu() - ld).abs().max()) < 2e-4
         assert float((out[f"depth_pred_s{i}_b1hw"].cpu() - torch.exp(ld)).abs().max()) < 1e-3
+
+
+def _whole_tensor_case(name, element=None):
+    """GPU outputs + intermediates of one full-size case and the torch-CPU oracle's on the same inputs (``element``: compare that
+    batch element only -- the oracle then runs on it alone; the GPU runs the whole batch)."""
+    import gpu_util as gu
+    from oracle import torch_cpu_ref as tref
+
+    model, inp, t, pyr = build_case(name)
+    b, k, h, w, D, seed, dec = CASES[name]
+    cv_gpu, vol_gpu, nodes_gpu = [], [], {}
+    hook = model.cost_volume_net.register_forward_hook(lambda m, i, o: cv_gpu.extend(o))
+    hook2 = model.cost_volume.register_forward_hook(lambda m, i, o: vol_gpu.append(o[0]))
+    if dec == "unet_pp":
+        orig = model.depth_decoder.forward
+        model.depth_decoder.forward = lambda feats: orig(feats, _nodes=nodes_gpu)
+    try:
+        out = model.forward_from_features(pyr, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"], t["src_Ks"],
+                                          t["cur_invK"], gu.hint_dict(t), return_mask=True)
+        torch.cuda.synchronize()
+    finally:
+        hook.remove()
+        hook2.remove()
+    sl = slice(None) if element is None else slice(element, element + 1)
+    sd = {kk: v.detach().cpu() for kk, v in model.state_dict().items()}
+    lin = lambda pre: [(sd[f"{pre}.net.{i}.weight"], sd[f"{pre}.net.{i}.bias"]) for i in (0, 2, 4)]
+    sub = lambda pre: {kk[len(pre):]: v for kk, v in sd.items() if kk.startswith(pre)}
+    ti = {n: torch.from_numpy(v)[sl] if (v.ndim and v.shape[0] == b) else torch.from_numpy(v) for n, v in inp.items()}
+    hint = {n: ti[n] for n in ("depth_hint_b1hw", "sampled_weights_b1hw", "depth_hint_mask_b1hw")}
+    prev = torch.get_num_threads()
+    torch.set_num_threads(max(8, prev))
+    nodes_cpu = {}
+    try:
+        vol, planes = tref.hint_volume_loop(ti["cur_feats"], ti["src_feats"], ti["src_extrinsics"], ti["src_poses"], ti["src_Ks"],
+                                            ti["cur_invK"], ti["min_depth"], ti["max_depth"], D, lin("cost_volume.mlp"), hint=hint,
+                                            hint_mlp=lin("cost_volume.hint_mlp"))
+        pyr_c = [p.cpu()[sl] for p in pyr]
+        cv = tref.cv_encoder(vol, pyr_c[1:], sub("cost_volume_net."))
+        if dec == "unet_pp":
+            dd = tref.depth_decoder_pp([pyr_c[0]] + cv, sub("depth_decoder."), nodes=nodes_cpu)
+        else:
+            dd = tref.skip_decoder_regression([pyr_c[0]] + cv, sub("depth_decoder."))
+    finally:
+        torch.set_num_threads(prev)
+    return dict(out=out, vol_gpu=vol_gpu[0], cv_gpu=cv_gpu, nodes_gpu=nodes_gpu, vol=vol, planes=planes, cv=cv, dec=dd,
+                nodes=nodes_cpu, sl=sl)
+
+
+def _assert_whole_tensors(c):
+    sl = c["sl"]
+    d = lambda a, b: float((a.cpu()[sl] - b).abs().max())
+    assert tuple(c["vol_gpu"][sl].shape) == tuple(c["vol"].shape) and d(c["vol_gpu"], c["vol"]) < 5e-5
+    assert len(c["cv_gpu"]) == len(c["cv"]) == 4
+    for a, b in zip(c["cv_gpu"], c["cv"]):
+        assert d(a, b) < 2e-4
+    for i in range(4):
+        ld = c["dec"][f"log_depth_pred_s{i}_b1hw"]
+        assert d(c["out"][f"log_depth_pred_s{i}_b1hw"], ld) < 2e-4
+        assert d(c["out"][f"depth_pred_s{i}_b1hw"], torch.exp(ld)) < 1e-3
+
+
+def test_cfg2_full_whole_tensors_vs_torch_cpu_oracle():
+    """DepthDecoderPP (F1: 292 GFLOP, the largest FLOP consumer of the full model) was pinned at full size
+    by 256 probes and sums only.  Here EVERY element of the cost volume, the four CVEncoder maps, all ten UNet++ node outputs
+    X_ij, the four log-depth maps and the four depth maps of the 640x480 full model is compared with the torch-CPU
+    restatement (oracle/torch_cpu_ref.py, pinned to the reference goldens).  Tolerances: volume 5e-5, feature maps and
+    UNet++ nodes 2e-4 (the nodes are O(1) activations), log depth 2e-4, depth 1e-3 (north star)."""
+    c = _whole_tensor_case("cfg2_full")
+    _assert_whole_tensors(c)
+    assert sorted(c["nodes_gpu"]) == sorted(c["nodes"]) and len(c["nodes"]) == 10
+    for name, want in c["nodes"].items():
+        got = c["nodes_gpu"][name].cpu()
+        assert tuple(got.shape) == tuple(want.shape), name
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) < 2e-4 * scale, (name, float((got - want).abs().max()), scale)
+
+
+def test_cfg5_small_d96_whole_tensors_vs_torch_cpu_oracle():
+    """the D = 96 portrait shape (384x512 image, 96x128 matching resolution, batch 2), one batch element,
+    every element of every tensor: volume, CVEncoder maps, log depth, depth."""
+    c = _whole_tensor_case("cfg5_small_d96", element=1)
+    _assert_whole_tensors(c)
