@@ -118,6 +118,10 @@ SIGNATURES = {
     "dt_mc_workspace_bytes": (_L, [_I, _I, _I]),
     "dt_mc_count": (_I, [_P, _P, _I, _I, _I, _F, C.POINTER(_I), C.POINTER(_I), _P, _P, _P]),
     "dt_mc_generate": (_I, [_P, _P, _I, _I, _I, _F, C.POINTER(_I), C.POINTER(_I), _P, _P, _P, _P, _I, _P]),
+    "dt_conv_wino4_pack_floats": (_L, [_I, _I]),
+    "dt_conv_wino4_pack_f32": (_I, [_P, _P, _I, _I, _P]),
+    "dt_conv2d_wino4_blocks": (_L, [C.POINTER(ConvDesc)]),
+    "dt_conv2d_wino4_f32": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "dt_program_begin": (_I, [_P]),
     "dt_program_input": (_I, [_P, _L]),
     "dt_program_mark": (_I, []),

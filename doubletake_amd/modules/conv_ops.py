@@ -141,6 +141,35 @@ def packed_weight_wino_split(conv: nn.Conv2d, device):
     return packed
 
 
+def packed_weight_wino4(conv: nn.Conv2d, device):
+    """F(4x4, 3x3) Winograd-domain weights (G g G^T, 36 positions) packed for conv_wino4_kernel; cached per weight version."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, device)
+    hit = getattr(conv, "_dt_pack_wino4", None)
+    if hit is not None and hit[0] == key:
+        _abi.wait_ready(hit[2], device)
+        return hit[1]
+    co, ci, k, k2 = w.shape
+    if (k, k2) != (3, 3) or conv.stride != (1, 1) or conv.groups != 1 or conv.dilation != (1, 1) or conv.padding != (1, 1):
+        raise NotImplementedError(f"Winograd path needs a 3x3 stride-1 pad-1 conv, got {conv}")
+    L = _abi.lib()
+    wd = w.detach().to(device=device, dtype=torch.float32).contiguous()
+    packed = torch.empty(int(L.dt_conv_wino4_pack_floats(co, ci)), device=device, dtype=torch.float32)
+    _abi.check(L.dt_conv_wino4_pack_f32(_abi.ptr(wd), _abi.ptr(packed), co, ci, _abi.current_stream(device)),
+               "dt_conv_wino4_pack_f32")
+    conv._dt_pack_wino4 = (key, packed, _abi.record_ready(device))
+    return packed
+
+
+#: OPT-IN: F(4x4, 3x3) instead of F(2x2, 3x3) for 3x3 stride-1 layers whose launch has at least this many 16x16-pixel x
+#: 32-channel workgroups (csrc/conv_wino4.hip: 2.25 instead of 4 multiplies per output pixel).  0 (default) = never: the kernel
+#: is correct and tested, but on gfx950 it measured 0.7-0.85x the speed of the F(2x2) kernel on every layer shape of the conv
+#: stacks at batch 1 and 8 (profiles/r6i_wino4_ab2.txt) -- neither kernel is bound by the matrix pipe (the fp32 MFMAs and the
+#: transform's vector instructions do not overlap, and F(4x4) has 2.3x the vector work per MFMA), see DESIGN.md 4.8.
+#: DT_CONV_WINO4_MIN_BLOCKS overrides.
+WINO4_MIN_BLOCKS = int(_os.environ.get("DT_CONV_WINO4_MIN_BLOCKS", "0"))
+
+
 #: arithmetic of the Winograd-domain products of the 3x3 stride-1 layers: "fp32" (default, exact fp32 MFMA) or the opt-in
 #: "split16" (fp16 hi/lo operand pairs on the fp16 matrix pipe, fp32 accumulation; csrc/conv_wino_split.hip).  Layers the
 #: split kernel does not take (fewer than SPLIT_MIN_BLOCKS workgroups, a source that is not a multiple of 16 channels,
@@ -191,7 +220,7 @@ def launch_config():
     module switches above and the library's settings token (plan objective, volume-kernel CU budget).  Replay mechanisms
     (utils/graphs.py, utils/program.py) bake those decisions in; the model keys its captured graphs / recorded programs on
     this, so a switch flipped afterwards leads to a new capture instead of a silent replay of the old choice."""
-    return (int(_abi.lib().dt_settings_token()), WINO_MIN_BLOCKS, CONV_PRECISION, SPLIT_MIN_BLOCKS, TRANSPOSED_TILING, PAIR_LAUNCH,
+    return (int(_abi.lib().dt_settings_token()), WINO_MIN_BLOCKS, WINO4_MIN_BLOCKS, CONV_PRECISION, SPLIT_MIN_BLOCKS, TRANSPOSED_TILING, PAIR_LAUNCH,
             HEAD_MULTI_LAUNCH, HEADS_IN_CONV)
 
 
@@ -219,7 +248,7 @@ def _conv_plan(srcs, conv, act, impl, L):
     enqueues ~45 conv launches per keyframe; with 4 keyframes in flight it needs 85 % of a step for that, so the per-call
     Python work is kept to key construction, one allocation and the ctypes call).  The key carries the strides and dtypes, so a
     hit implies the same NHWC fp32 layout that was validated on the miss."""
-    key = (act, impl, WINO_MIN_BLOCKS, CONV_PRECISION, tuple((t.shape, t.stride(), t.dtype, up) for t, up in srcs))
+    key = (act, impl, WINO_MIN_BLOCKS, WINO4_MIN_BLOCKS, CONV_PRECISION, tuple((t.shape, t.stride(), t.dtype, up) for t, up in srcs))
     cache = conv.__dict__.get("_dt_plans")
     if cache is None:
         cache = conv.__dict__["_dt_plans"] = {}
@@ -259,6 +288,9 @@ def _conv_plan(srcs, conv, act, impl, L):
     wino_blocks = n * ((d.h_out + 7) // 8) * ((d.w_out + 15) // 16) * (co // 32) if (k == 3 and st == 1 and co % 32 == 0) else 0
     if impl == "mfma" and wino_blocks > 0 and WINO_MIN_BLOCKS > 0 and wino_blocks >= WINO_MIN_BLOCKS:
         impl = "wino"
+    if impl == "wino" and CONV_PRECISION == "fp32" and WINO4_MIN_BLOCKS > 0 and conv.padding_mode in ("zeros", "replicate") \
+            and int(L.dt_conv2d_wino4_blocks(C.byref(d))) >= WINO4_MIN_BLOCKS:
+        impl = "wino4"
     if impl == "wino" and CONV_PRECISION == "split16" and wino_blocks >= SPLIT_MIN_BLOCKS \
             and conv.padding_mode in ("zeros", "replicate") and L.dt_conv2d_wino_split_supported(C.byref(d)):
         impl = "wino_split"
@@ -302,6 +334,11 @@ def conv2d(srcs, conv: nn.Conv2d, act=ACT_NONE, residual=None, impl="mfma"):
         rc = L.dt_conv2d_wino_f32(dref, p0, p1, p2, wp.data_ptr(), pbias, pres, out.data_ptr(), stream)
         if rc:
             _abi.check(rc, "dt_conv2d_wino_f32")
+    elif impl == "wino4":
+        wp = packed_weight_wino4(conv, dev)
+        rc = L.dt_conv2d_wino4_f32(dref, p0, p1, p2, wp.data_ptr(), pbias, pres, out.data_ptr(), stream)
+        if rc:
+            _abi.check(rc, "dt_conv2d_wino4_f32")
     elif impl == "mfma":
         wp = packed_weight(conv, dev, transposed=bool(d.transposed))
         rc = L.dt_conv2d_f32(dref, p0, p1, p2, wp.data_ptr(), pbias, pres, out.data_ptr(), stream)

@@ -514,6 +514,23 @@ int dt_sparse_mc_generate(int* dir, unsigned char* touch, int nb, float voxel_si
                           int* count2, int capacity, int num_slots, float isolevel, float weight_threshold, const int* slot_offsets,
                           float* verts_v3, float* vert_weights_v, int64_t* faces_f3, int64_t* ids_v, int num_verts, dt_stream_t s);
 
+/* ---- Winograd F(4x4, 3x3): the chip-filling 3x3 stride-1 layers with 2.25 multiplies per output pixel (csrc/conv_wino4.hip) ---
+ * replaces: the same reference convolutions as dt_conv2d_wino_f32 (modules/layers.py:77-94 BasicBlock convs,
+ * modules/networks_fast.py:17-40 ConvBlock convs, modules/networks.py:20-85 UNet++ nodes) -- same descriptor, same fused
+ * concat / nearest-x2 / padding / bias / residual / activation semantics, exact-fp32 MFMA.  Output blocks are 16 x 16 pixels x
+ * 32 channels (384-thread workgroups): meant for launches with enough blocks to fill the chip (dt_conv2d_wino4_blocks; the
+ * host side picks F(2x2) below its threshold).  fp32 rounding is amplified more than by F(2x2) (about 5e-6 mean, 3e-5 worst per
+ * layer on O(1) activations): inside the path's tolerances, checked by the whole-tensor parity tests.
+ *   dt_conv_wino4_pack_floats(c_out, c_in)   floats of the packed weights (c_out * c_in * 36), 0 for unsupported channel counts
+ *   dt_conv_wino4_pack_f32                   OIHW 3x3 -> U = G g G^T (computed in double, rounded once), packed for the kernel
+ *   dt_conv2d_wino4_blocks(desc)             workgroups the launch would have; 0 = shape not supported
+ *   dt_conv2d_wino4_f32                      the convolution; `packed_w` from dt_conv_wino4_pack_f32 */
+int64_t dt_conv_wino4_pack_floats(int c_out, int c_in);
+int dt_conv_wino4_pack_f32(const float* W_oihw, float* packed, int c_out, int c_in, dt_stream_t s);
+int64_t dt_conv2d_wino4_blocks(const dt_conv_desc* d);
+int dt_conv2d_wino4_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* packed_w,
+                        const float* bias, const float* residual, float* out, dt_stream_t s);
+
 /* ---- launch programs: one host call per model step ------------------------------------------------------------------
  * replaces: nothing the reference has as a function -- it is the host side of the call sequence of
  * DepthModelCVHint.forward (experiment_modules/doubletake_model.py:341-349,375-423: cost volume -> CVEncoder -> depth

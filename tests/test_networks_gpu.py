@@ -544,3 +544,52 @@ def test_coarse_heads_inside_the_conv_grid_are_bit_identical(h0, w0, with_depth)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     blocks = ((2 * h0 + 7) // 8) * ((2 * w0 + 15) // 16) * 2
     assert n_fused == n_plain - (1 if blocks >= 2 * cus else 0)
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 16, 32, 13, 21, "zeros", 1, False),      # ragged extent (one partial 16x16 block in each direction), one source
+    (2, 24, 64, 16, 32, "zeros", 2, True),       # batch 2, two sources, the second nearest-upsampled, residual + bias
+    (1, 64, 32, 24, 40, "replicate", 1, False),  # replicate padding
+    (1, 64, 64, 120, 160, "zeros", 1, True),     # 8 x 10 blocks x 2 channel blocks, last block row half outside the image
+    (1, 192, 64, 48, 64, "zeros", 3, True),      # three sources (UNet++ node input), the first nearest-upsampled
+    (2, 128, 128, 96, 128, "zeros", 1, False),   # cfg3-like level: 384 blocks, XCD-contiguous order
+])
+def test_winograd_f4x4_conv_vs_direct(shape):
+    """conv_wino4_kernel (F(4x4,3x3) on v_mfma_f32_16x16x4_f32, csrc/conv_wino4.hip) against the direct one-thread-per-output
+    conv and against the F(2x2) kernel on the same inputs: fused concat / nearest x2 / padding / bias / residual / activation.
+    Tolerance: F(4x4) amplifies fp32 rounding (numpy model of the same arithmetic: 3e-5 worst case on O(1) outputs)."""
+    import gpu_util as gu
+    from doubletake_amd.modules import conv_ops as ops
+
+    n, cin, cout, h, w, pad_mode, nsrc, with_res = shape
+    dev = gu.dev()
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1, padding_mode=pad_mode).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(syn.hash_normalish(tuple(conv.weight.shape), 5) * (1.0 / np.sqrt(9.0 * cin))))
+        conv.bias.copy_(torch.from_numpy(syn.hash_normalish((cout,), 6) * 0.1))
+    mk = lambda c, hh, ww, seed: ops.as_nhwc(torch.from_numpy(syn.hash_normalish((n, c, hh, ww), seed)).to(dev))
+    if nsrc == 1:
+        srcs = [(mk(cin, h, w, 1), False)]
+    elif nsrc == 2:
+        srcs = [(mk(cin - 8, h, w, 1), False), (mk(8, h // 2, w // 2, 2), True)]
+    else:
+        srcs = [(mk(cin // 3, h // 2, w // 2, 1), True), (mk(cin // 3, h, w, 2), False), (mk(cin // 3, h, w, 3), False)]
+    res = mk(cout, h, w, 4) if with_res else None
+    prev = ops.WINO4_MIN_BLOCKS
+    for act in (ops.ACT_LRELU02, ops.ACT_ELU, ops.ACT_NONE):
+        want = ops.conv2d(srcs, conv, act=act, residual=res, impl="simple")
+        ops.WINO4_MIN_BLOCKS = 0
+        try:
+            f2 = ops.conv2d(srcs, conv, act=act, residual=res, impl="wino")
+            ops.WINO4_MIN_BLOCKS = 1
+            got = ops.conv2d(srcs, conv, act=act, residual=res, impl="wino")
+            again = ops.conv2d(srcs, conv, act=act, residual=res, impl="wino")
+        finally:
+            ops.WINO4_MIN_BLOCKS = prev
+        torch.cuda.synchronize()
+        assert got.shape == want.shape and torch.equal(got, again)
+        scale = max(float(want.abs().max()), 1.0)
+        err = float((got - want).abs().max())
+        assert err < 4e-5 * scale, (act, err, scale)
+        assert float((f2 - want).abs().max()) < 4e-6 * max(scale, 5.0)
+        assert not torch.equal(got, f2)  # (the F(4x4) kernel really ran: its rounding differs from F(2x2)'s)
