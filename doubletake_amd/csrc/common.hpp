@@ -34,10 +34,11 @@ int device_cu_count();
 //     own parameter types -- are appended to the program, and the launch still executes.  dt_program_launch then re-issues the
 //     recorded launches with one host call (hipLaunchKernel per node, none of the planning above it).
 void note_launch();
-// process-wide settings that change which kernels / grids the launchers pick (0: dt_conv_set_plan_objective, 1:
-// dt_cv_mlp_set_cu_budget) report their value here: replay mechanisms (hipGraphs, launch programs) bake those choices in at
-// capture time and key their caches on dt_settings_token()
-void note_setting(int which, int value);
+// process-wide settings that change which kernels / grids the launchers pick -- the values in force (conv.hip: the plan
+// objective mask; cv_mlp_mfma.hip: the volume kernel's CU budget, 0 = whole device).  dt_settings_token() combines them: replay
+// mechanisms (hipGraphs, launch programs) bake those choices in at capture time and key their caches on the token
+int conv_plan_objective_value();
+int mlp_cu_budget_value();
 bool recording_on(hipStream_t s);  // this thread records launches of stream s
 void record_node(const void* func, dim3 grid, dim3 block, size_t shmem, int nargs, const void* const* arg_ptrs,
                  const size_t* arg_sizes, const size_t* arg_aligns);

@@ -1363,6 +1363,7 @@ static int device_cus() { return device_cu_count(); }
 // 0 = latency (default).  DT_CONV_OBJ presets it.
 static std::atomic<int> g_conv_obj{[] { const char* e = getenv("DT_CONV_OBJ"); return e ? atoi(e) : 0; }()};
 static inline int conv_obj() { return g_conv_obj.load(std::memory_order_relaxed); }
+int conv_plan_objective_value() { return conv_obj(); }
 
 // Number of workgroups P that share one output block of a K-split kernel.  Measured on the K-split kernels
 // (scripts/conv_quantisation.py, profiles/r2p_conv_quantisation.txt): a launch lasts about
@@ -1823,7 +1824,6 @@ int dt_conv2d_pair_f32(const dt_conv_desc* da, const dt_conv_desc* db, const flo
 
 int dt_conv_set_plan_objective(int mask) {
   g_conv_obj.store(mask < 0 ? 0 : mask, std::memory_order_relaxed);
-  note_setting(0, conv_obj());
   return conv_obj();
 }
 

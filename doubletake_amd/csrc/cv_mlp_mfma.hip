@@ -927,6 +927,7 @@ static const int* mlp_tile_order(int h, int w, hipStream_t st) {
 static int g_mlp_waves = [] { const char* e = getenv("DT_MLP_WAVES"); return (e && e[0] == '4') ? 4 : 8; }();
 // compute-unit budget of the volume kernel (dt_cv_mlp_set_cu_budget; 0 = the whole device); DT_MLP_CUS presets it
 static std::atomic<int> g_mlp_cu_budget{[] { const char* e = getenv("DT_MLP_CUS"); return e ? atoi(e) : 0; }()};
+int mlp_cu_budget_value() { return g_mlp_cu_budget.load(std::memory_order_relaxed); }
 static int num_cus() {
   const int dev = device_cu_count(), b = g_mlp_cu_budget.load(std::memory_order_relaxed);
   return (b > 0 && b < dev) ? std::max(8, b / 8 * 8) : dev;
@@ -1037,7 +1038,6 @@ int dt_cv_mlp_hint_f32(const float* cur, const float* src, const float* params, 
 
 int dt_cv_mlp_set_cu_budget(int cus) {
   g_mlp_cu_budget.store(cus > 0 ? cus : 0, std::memory_order_relaxed);
-  note_setting(1, num_cus());
   return num_cus();
 }
 

@@ -22,8 +22,7 @@ int fail(const char* fmt, ...) {
 
 static std::atomic<long long> g_launches{0};
 void note_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
-static std::atomic<int> g_settings[2] = {{-1}, {-1}};  // (-1: still at the value the environment preset, never set by a call)
-void note_setting(int which, int value) { g_settings[which & 1].store(value, std::memory_order_relaxed); }
+
 
 int device_cu_count() {
   static std::mutex mtx;
@@ -91,10 +90,7 @@ const char* dt_last_error(void) { return err_buf(); }
 
 int64_t dt_kernel_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
 
-int64_t dt_settings_token(void) {
-  const int64_t a = g_settings[0].load(std::memory_order_relaxed) + 1, b = g_settings[1].load(std::memory_order_relaxed) + 1;
-  return a | (b << 24);
-}
+int64_t dt_settings_token(void) { return (int64_t)conv_plan_objective_value() | ((int64_t)mlp_cu_budget_value() << 24); }
 
 int dt_device_count(void) {
   int n = 0;

@@ -42,8 +42,9 @@ int dt_device_count(void);
 /* Kernels launched by this library in this process so far (all streams, all entry points): lets a caller report the
  * launch count of a step as the difference of two reads (bench.py roofline_conv.launches). */
 int64_t dt_kernel_launch_count(void);
-/* A value that identifies the process-wide settings that change kernel selection or launch geometry (the values last given
- * to dt_conv_set_plan_objective and dt_cv_mlp_set_cu_budget; "never set" is a value of its own).  Replay mechanisms above the
+/* A value that identifies the process-wide settings that change kernel selection or launch geometry (the plan objective mask
+ * and the volume kernel's CU budget in force, whether preset by the environment or given to dt_conv_set_plan_objective /
+ * dt_cv_mlp_set_cu_budget).  Replay mechanisms above the
  * ABI (captured hipGraphs, launch programs) bake those choices in; keying their caches on this token keeps a replay from
  * silently using the old ones, and setting a value back makes the old captures valid again. */
 int64_t dt_settings_token(void);
