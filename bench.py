@@ -767,8 +767,14 @@ def main():
         if fuser is None:
             return None
         b = CFG["batch"]
-        j = [((frame_idx * world + rank) * b + i) % POOL for i in range(b)]  # global keyframe index -> camera
-        sl = slice(j[0], j[0] + 1) if b == 1 else torch.as_tensor(j, device=device)
+        j0 = ((frame_idx * world + rank) * b) % POOL  # global keyframe index -> camera
+        if j0 + b <= POOL:
+            sl = slice(j0, j0 + b)
+        else:  # the batch wraps around the camera pool: index tensors are built once per start index (an index list uploaded
+            #    from pageable host memory synchronises the device: before round 6 every batched step did that)
+            sl = wrap_index.get(j0)
+            if sl is None:
+                sl = wrap_index[j0] = torch.as_tensor([(j0 + i) % POOL for i in range(b)], device=device)
         return out["depth_pred_s0_b1hw"], K_pool16[sl], T_pool16[sl]
 
     pipe = make_pipeline(args.streams)
