@@ -591,10 +591,9 @@ def main():
                     help="arithmetic of the 3x3 stride-1 conv layers: exact fp32 MFMA (default, the headline) or the opt-in "
                          "split-precision Winograd kernel (fp16 hi/lo products on the fp16 matrix pipe, fp32 accumulation)")
     ap.add_argument("--streams", type=int, default=None,
-                    help="run consecutive keyframes on this many HIP streams (frames are independent in this workload; the "
-                         "TSDF integrations stay in frame order).  Default: 4 for the batch-1 configs, 1 for the batched ones (cfg3 "
-                         "batch 8, cfg5 batch 2: a batch already fills the chip and frames in flight only add contention: "
-                         "profiles/r5k_bench_all_configs.txt).  The dominant kernel's roofline figure comes from the "
+                    help="keyframe batches in flight = lanes of parallel.KeyframePipeline (batches are independent in this workload; "
+                         "the TSDF integrations stay in order).  Default: 4 for the batch-1 DoubleTake-small shapes, 3 for the full "
+                         "model and the batched shapes (profiles/r6n_lanes_all_configs.txt).  The dominant kernel's roofline figure comes from the "
                          "single-stream leg of the same run (with several frames in flight an event bracket measures the schedule)")
     ap.add_argument("--conv-plan", default="auto",
                     help="plan objective of the conv launchers: 'latency' (one keyframe at a time), 'throughput' (several keyframes "
@@ -630,7 +629,11 @@ def main():
     CFG.clear()
     CFG.update(CONFIGS[args.config])
     if args.streams is None:
-        args.streams = DEFAULT_STREAMS if CFG["batch"] == 1 else 1
+        # keyframe batches in flight: 4 for the batch-1 DoubleTake-small shapes (the headline), 3 for the full model and the
+        # batched shapes -- round 6: with the model step one C call and the pipeline's back-pressure, lanes pay at every
+        # shape (cfg3 full B=8: 602 -> 642 frames/s, cfg5 full: 414 -> 517; profiles/r6n_lanes_all_configs.txt), where the
+        # eager loop of round 5 lost with more than one
+        args.streams = DEFAULT_STREAMS if (CFG["batch"] == 1 and CFG["decoder"] == "skip") else 3
     default_cfg = args.config == "cfg2_small"
 
     from doubletake_amd import hwqueues  # (imports nothing heavy)

@@ -91,6 +91,8 @@ def main():
         model.use_feature_cache = True
         model.enable_hip_graphs("graphs" in mode)
         model.enable_launch_programs("programs" in mode)
+        if "eagerenc" in mode:
+            model._recorded_encoder = None  # (experiment: the model step from a program, the encoder pass eager)
         fuser = OurFuser(None, 0.04, 3.0, bounds=bd)
         timer = loops.FrameTimer()
         warm = 8
