@@ -929,7 +929,7 @@ def main():
         frames = args.steps * CFG["batch"] * world
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the figure comes from
         # the last scripts/collect_pmc.sh pass -- and only while the kernel source it was measured on is the one built now
-        traffic, traffic_tag, executed = None, None, None
+        traffic, traffic_tag, executed, rocprof_ns, rocprof_file = None, None, None, None, None
         tf = os.path.join(REPO, "profiles", "roofline_traffic.json")
         if os.path.isfile(tf) and default_cfg and args.mlp_precision == "fp32":
             try:
@@ -941,6 +941,7 @@ def main():
                     traffic = rec.get("cv_mlp_mfma_kernel_hbm_bytes_per_launch")
                     traffic_tag = rec.get("profile_tag")
                     executed = rec.get("executed_mfma_flops_per_launch")
+                    rocprof_ns, rocprof_file = rec.get("rocprof_avg_launch_ns"), rec.get("rocprof_stats_file")
             except Exception:
                 traffic = None
         result = {
@@ -1000,6 +1001,11 @@ def main():
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic,
                 "traffic_profile": traffic_tag,
+                # the same fraction from the kernel's average under rocprofv3 --kernel-trace --stats (the figure profiles/
+                # reproduces; tracing adds 1-2.5 % to the launch), from the same hash-checked record as `traffic`
+                "frac_rocprof": (flops / (rocprof_ns * 1e-9) / 1e12 / PEAK_F32_MFMA_TFLOPS) if rocprof_ns else None,
+                "avg_launch_ms_rocprof": (rocprof_ns * 1e-6) if rocprof_ns else None,
+                "rocprof_stats_file": rocprof_file,
                 "algorithmic_flops_per_launch": flops,
                 "avg_launch_ms": kern_ms,
                 "measured_in": ("single-stream leg of this run: same process, inputs and launches, HIP events on the kernel's "

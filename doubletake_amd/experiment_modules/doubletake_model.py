@@ -472,10 +472,7 @@ class _HotPathDepthModel(nn.Module):
         """CVEncoder + depth decoder + exp on the volume of volume_stage -> the reference's output dict."""
         cv_feats = self.cost_volume_net(cost_volume, cur_feats[self.matching_scale:])
         feats = list(cur_feats[: self.matching_scale]) + cv_feats
-        if isinstance(self.depth_decoder, SkipDecoderRegression):
-            depth_outputs = self.depth_decoder(feats, with_depth=True)  # heads write exp(log depth) themselves
-        else:
-            depth_outputs = self.depth_decoder(feats)
+        depth_outputs = self.depth_decoder(feats, with_depth=True)  # heads write exp(log depth) themselves
         for k in list(depth_outputs.keys()):
             if not k.startswith("log_depth"):
                 continue

@@ -88,10 +88,11 @@ class CVEncoder(nn.Module):
 class _Head(nn.Sequential):
     """output_i = Sequential(BasicBlock | Identity, Conv2d(c, 1, 1)) (modules/networks.py:60-63)."""
 
-    def run(self, x, impl="mfma"):
+    def run(self, x, impl="mfma", with_exp=False):
+        """with_exp: (log depth, exp(log depth)) from the head's own launch (dt_conv1x1_head_f32 writes both)."""
         if isinstance(self[0], BasicBlock):
             x = self[0].run([(x, False)], impl=impl)
-        return ops.conv1x1_head(x, self[1])
+        return ops.conv1x1_head(x, self[1], with_exp=with_exp)
 
 
 class DepthDecoderPP(nn.Module):
@@ -131,9 +132,11 @@ class DepthDecoderPP(nn.Module):
                 )
 
     @torch.no_grad()
-    def forward(self, input_features, _impl="mfma", _nodes=None):
+    def forward(self, input_features, _impl="mfma", _nodes=None, with_depth=False):
         """_nodes: optional dict that receives the UNet++ node outputs X_ij under their ModuleDict names
-        (``in_conv_{i}{j}``) -- what a forward hook on the reference's ``convs[name]`` sees (parity tests)."""
+        (``in_conv_{i}{j}``) -- what a forward hook on the reference's ``convs[name]`` sees (parity tests).
+        with_depth (extension used by DepthModelCVHint, like SkipDecoderRegression's): the head launches also write
+        depth_pred_s{i}_b1hw = exp(log depth), saving the four exp passes of experiment_modules/doubletake_model.py:410-418."""
         prev = [ops.as_nhwc(f) for f in input_features]
         outputs = []
         pending = {}
@@ -153,5 +156,11 @@ class DepthDecoderPP(nn.Module):
                 # only the surviving evaluation is computed here.
                 pending[i] = out
             prev = outputs[::-1]
-        return {f"log_depth_pred_s{i}_b1hw": self.convs[f"output_{i}"].run(pending[i], impl=_impl)
-                for i in sorted(pending, reverse=True)}
+        out = {}
+        for i in sorted(pending, reverse=True):
+            res = self.convs[f"output_{i}"].run(pending[i], impl=_impl, with_exp=with_depth)
+            if with_depth:
+                out[f"log_depth_pred_s{i}_b1hw"], out[f"depth_pred_s{i}_b1hw"] = res
+            else:
+                out[f"log_depth_pred_s{i}_b1hw"] = res
+        return out

@@ -3,6 +3,7 @@
 roofline.traffic -- from a PMC summary written by scripts/pmc_summary.py.
 
     python scripts/make_roofline_traffic.py r3c        # reads profiles/r3c_pmc_summary.json
+    python scripts/make_roofline_traffic.py r6z profiles/r6z_bench_kernel_stats.csv   # + the kernel's rocprofv3 average
 
 The record carries the hash of the kernel source the counters were collected on; bench.py reports the figure only while
 that hash equals the source it runs (so a stale pass can never be attributed to a newer kernel).  Run this after every
@@ -22,6 +23,15 @@ def main():
     rec = summ[name]
     fetch_kb, write_kb = rec["FETCH_SIZE"], rec["WRITE_SIZE"]
     src = open(os.path.join(REPO, "doubletake_amd", "csrc", "cv_mlp_mfma.hip"), "rb").read()
+    rocprof_ns = rocprof_calls = stats_file = None
+    if len(sys.argv) > 2:  # kernel stats of a rocprofv3 --kernel-trace --stats run of bench.py on the same library
+        import csv
+
+        stats_file = sys.argv[2]
+        for row in csv.DictReader(open(os.path.join(REPO, stats_file) if not os.path.isabs(stats_file) else stats_file)):
+            if "cv_mlp_mfma_kernel" in row["Name"]:
+                rocprof_ns, rocprof_calls = float(row["AverageNs"]), int(row["Calls"])
+                break
     out = {
         "profile_tag": tag,
         "kernel": name,
@@ -41,6 +51,9 @@ def main():
         "executed_mfma_flops_per_launch": (rec["SQ_VALU_MFMA_BUSY_CYCLES"] / 64.0 * 4096.0) if rec.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
         "GRBM_GUI_ACTIVE_per_xcd": (rec["GRBM_GUI_ACTIVE"] / 8.0) if rec.get("GRBM_GUI_ACTIVE") else None,
         "pmc_pass_duration_ns": rec.get("_duration_ns"),
+        # the kernel's average under rocprofv3 --kernel-trace --stats (the figure profiles/ reproduces; the
+        # HIP-event time bench.py measures live is 1-2.5 % shorter) travels with the record: bench.py prints frac_rocprof from it
+        "rocprof_avg_launch_ns": rocprof_ns, "rocprof_calls": rocprof_calls, "rocprof_stats_file": stats_file,
         "note": "bench.py reports this figure only while kernel_source_sha16 equals the hash of "
                 "doubletake_amd/csrc/cv_mlp_mfma.hip (otherwise traffic = null: the kernel changed since the counters were collected)",
     }

@@ -287,7 +287,7 @@ def _whole_tensor_case(name, element=None):
     hook2 = model.cost_volume.register_forward_hook(lambda m, i, o: vol_gpu.append(o[0]))
     if dec == "unet_pp":
         orig = model.depth_decoder.forward
-        model.depth_decoder.forward = lambda feats: orig(feats, _nodes=nodes_gpu)
+        model.depth_decoder.forward = lambda feats, **kw: orig(feats, _nodes=nodes_gpu, **kw)
     try:
         out = model.forward_from_features(pyr, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"], t["src_Ks"],
                                           t["cur_invK"], gu.hint_dict(t), return_mask=True)
