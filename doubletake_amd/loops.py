@@ -2,6 +2,8 @@
 
 ``run_incremental_scan``  -- reference test_incremental.py:172-372: frame t's hint is rendered from the TSDF fused
                             from frames < t (marching cubes -> depth render -> weight sampling), then model, then fuse.
+``run_incremental_scans`` -- several such scans in flight on one GPU (``IncrementalScan`` objects on HIP-stream lanes):
+                            scans are independent, the frames of one scan are not.
 ``two_pass_fns``          -- reference test_offline_two_pass.py:26-131 (first pass, empty hints, hint TSDF at
                             0.04 m / 3 m) and :292-500 (second pass, hints from the finished first-pass mesh) as the
                             two step functions ``parallel.run_two_pass`` shards over GPUs.
@@ -115,43 +117,49 @@ def matching_lookahead(model):
     return run
 
 
-def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fused_hint=True, mask_pred_depth=False,
-                         on_frame=None, timer: FrameTimer | None = None, lookahead=None):
-    """One scan of the incremental (online) mode; batch size 1 (reference test_incremental.py:25).
+class IncrementalScan:
+    """One scan of the incremental (online) mode as a step-able object: ``step()`` processes the next frame on torch's CURRENT
+    stream (hint from the TSDF fused so far -> model -> fuse) and returns False once the scan is exhausted.
+    ``run_incremental_scan`` drives one of these to the end; ``run_incremental_scans`` keeps several scans in flight on HIP
+    streams (different scans do not depend on each other; the frames of one scan do).  Arguments: see run_incremental_scan."""
 
-    batches: iterable of (cur_data, src_data); cur_data carries K_s0_b44 / invK_s0_b44 / cam_T_world_b44 /
-    world_T_cam_b44 / K_full_depth_b44 (+ whatever model_fn reads).  The hint entries (depth_hint_b1hw,
-    depth_hint_mask_b1hw, depth_hint_mask_b_b1hw, sampled_weights_b1hw) are written into cur_data here.
-    fused_hint: marching-cubes soup -> raster -> one back-project/sample/threshold kernel (4 launches) instead of the
-    reference-shaped sequence over a merged mesh.  timer: a FrameTimer that receives hint_time / model_time per frame
-    (test_incremental.py:205,256-258,274-288).  lookahead: callable(next_cur_data, next_src_data) run before the model of
-    the current frame -- work of frame t+1 that does not depend on frame t's result (``matching_lookahead``: its matching
-    features) and can fill the chip beside frame t's latency-bound kernels.  Returns the number of frames fused."""
-    H2, W2 = render_hw
-    renderer = None if fused_hint else MeshDepthRenderer(H2, W2)
-    n = 0
+    def __init__(self, model_fn, fuser, batches, render_hw, fuse_size=None, fused_hint=True, mask_pred_depth=False,
+                 on_frame=None, timer: FrameTimer | None = None, lookahead=None):
+        self.model_fn, self.fuser = model_fn, fuser
+        self.H2, self.W2 = render_hw
+        self.fuse_size, self.fused_hint, self.mask_pred_depth = fuse_size, fused_hint, mask_pred_depth
+        self.on_frame, self.timer, self.lookahead = on_frame, timer, lookahead
+        self.renderer = None if fused_hint else MeshDepthRenderer(self.H2, self.W2)
+        self.frames = 0
+        self._it = iter(batches)
+        self._next = self._pull() if lookahead is not None else None  # (a lookahead needs the batch after the current one)
 
-    def with_next(it):
-        it = iter(it)
+    def _pull(self):
         try:
-            cur = next(it)
+            return next(self._it)
         except StopIteration:
-            return
-        for nxt in it:
-            yield cur, nxt
-            cur = nxt
-        yield cur, None
+            return None
 
-    for i, ((cur_data, src_data), nxt) in enumerate(with_next(batches) if lookahead is not None else ((b, None) for b in batches)):
+    @torch.no_grad()
+    def step(self):
+        # (without a lookahead a batch is pulled when its frame starts: a lazy loader is never asked for more than the loop
+        #  consumes; with one, the batch after the current frame is pulled first)
+        item = self._next if self.lookahead is not None else self._pull()
+        if item is None:
+            return False
+        (cur_data, src_data), i = item, self.frames
+        nxt = self._pull() if self.lookahead is not None else None
+        fuser, timer, lookahead = self.fuser, self.timer, self.lookahead
+        H2, W2 = self.H2, self.W2
         if cur_data["cam_T_world_b44"].shape[0] != 1:
             raise ValueError("the incremental mode needs batch size 1 (frame t depends on the TSDF after frame t-1)")
         if i > 0:
             if timer is not None:
                 timer.start("hint_time")
-            if fused_hint:
+            if self.fused_hint:
                 prepare_mesh_hint_fused(fuser, cur_data, H2, W2)
             else:
-                prepare_mesh_hint(fuser, renderer, cur_data, H2, W2)
+                prepare_mesh_hint(fuser, self.renderer, cur_data, H2, W2)
             if timer is not None:
                 timer.stop("hint_time")
         else:
@@ -169,7 +177,7 @@ def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fu
         if timer is not None:
             timer.start("model_time")
         try:
-            outputs = model_fn(cur_data, src_data)
+            outputs = self.model_fn(cur_data, src_data)
         finally:
             # the one-shot hook belongs to THIS frame: if model_fn raised or never went through the owner's forward, a
             # stale closure over the next batch must not fire on a later, unrelated forward
@@ -178,12 +186,86 @@ def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fu
             stale()  # (model_fn did not consume it: run the lookahead now, as without an owner)
         if timer is not None:
             timer.stop("model_time")
-        depth = _depth_for_fusion(outputs, fuse_size, mask_pred_depth, per_view_mask=True)
+        depth = _depth_for_fusion(outputs, self.fuse_size, self.mask_pred_depth, per_view_mask=True)
         fuser.fuse_frames(depth, cur_data["K_full_depth_b44"], cur_data["cam_T_world_b44"], None)
-        n += 1
-        if on_frame is not None:
-            on_frame(i, cur_data, outputs)
-    return n
+        self.frames += 1
+        if self.on_frame is not None:
+            self.on_frame(i, cur_data, outputs)
+        self._next = nxt
+        return True
+
+
+def run_incremental_scan(model_fn, fuser, batches, render_hw, fuse_size=None, fused_hint=True, mask_pred_depth=False,
+                         on_frame=None, timer: FrameTimer | None = None, lookahead=None):
+    """One scan of the incremental (online) mode; batch size 1 (reference test_incremental.py:25).
+
+    batches: iterable of (cur_data, src_data); cur_data carries K_s0_b44 / invK_s0_b44 / cam_T_world_b44 /
+    world_T_cam_b44 / K_full_depth_b44 (+ whatever model_fn reads).  The hint entries (depth_hint_b1hw,
+    depth_hint_mask_b1hw, depth_hint_mask_b_b1hw, sampled_weights_b1hw) are written into cur_data here.
+    fused_hint: marching-cubes soup -> raster -> one back-project/sample/threshold kernel (4 launches) instead of the
+    reference-shaped sequence over a merged mesh.  timer: a FrameTimer that receives hint_time / model_time per frame
+    (test_incremental.py:205,256-258,274-288).  lookahead: callable(next_cur_data, next_src_data) run before the model of
+    the current frame -- work of frame t+1 that does not depend on frame t's result (``matching_lookahead``: its matching
+    features) and can fill the chip beside frame t's latency-bound kernels.  Returns the number of frames fused."""
+    scan = IncrementalScan(model_fn, fuser, batches, render_hw, fuse_size=fuse_size, fused_hint=fused_hint,
+                           mask_pred_depth=mask_pred_depth, on_frame=on_frame, timer=timer, lookahead=lookahead)
+    while scan.step():
+        pass
+    return scan.frames
+
+
+def run_incremental_scans(scans, in_flight=3, device=None, max_lead="auto"):
+    """Several scans of the incremental mode IN FLIGHT on one GPU (round 6).  Inside a scan frame t needs the TSDF after
+    frame t-1, so one scan is a chain of latency-bound kernels that leaves most of the chip idle (0.84 of the time at
+    512x384); different scans are independent.  ``scans``: ``IncrementalScan`` objects (each with its own fuser; the model --
+    and its feature cache, keyed by scan id -- may be shared).  Scan j runs on lane j % in_flight (a HIP stream), one frame
+    per scan per turn, round-robin; a lane is only ever given frames of its own scans, so stream order keeps every scan's
+    frames in sequence and no cross-scan ordering is needed.  Results per scan are bit-identical to running it alone
+    (same kernels, same order; the conv plan objective is process-wide: pass scans built under the one you want).
+    max_lead: back-pressure, as parallel.KeyframePipeline (frames the host may be ahead of the GPU; "auto" = in_flight + 1).
+    Returns the list of frames fused per scan."""
+    scans = list(scans)
+    if not scans:
+        return []
+    if device is None:
+        device = scans[0].fuser.tsdf_fuser_pred.tsdf.device if hasattr(scans[0].fuser, "tsdf_fuser_pred") else torch.device("cuda")
+    device = torch.device(device)
+    lanes = max(1, min(int(in_flight), len(scans)))
+    cuda = device.type == "cuda"
+    streams = None
+    if cuda and lanes > 1:
+        from . import hwqueues
+
+        hwqueues.check(lanes)
+        caller = torch.cuda.current_stream(device)
+        streams = [torch.cuda.Stream(device) for _ in range(lanes)]
+        for st in streams:
+            st.wait_stream(caller)
+    lead = (lanes + 1) if max_lead == "auto" else int(max_lead or 0)
+    pending = []
+    active = list(range(len(scans)))
+    while active:
+        still = []
+        for j in active:
+            if cuda and lead and len(pending) >= lead:
+                pending.pop(0).synchronize()
+            if streams is None:
+                more = scans[j].step()
+            else:
+                with torch.cuda.stream(streams[j % lanes]):
+                    more = scans[j].step()
+            if cuda and lead:
+                ev = torch.cuda.Event()
+                ev.record(streams[j % lanes] if streams is not None else torch.cuda.current_stream(device))
+                pending.append(ev)
+            if more:
+                still.append(j)
+        active = still
+    if streams is not None:
+        cur = torch.cuda.current_stream(device)
+        for st in streams:
+            cur.wait_stream(st)
+    return [s.frames for s in scans]
 
 
 @torch.no_grad()

@@ -190,3 +190,73 @@ def test_hint_sampling_fp32_vs_half_model_differ_only_at_the_weight_cut():
         up = torch.nn.functional.interpolate(d, size=(H, W), mode="nearest")
         fuser.fuse_frames(up, tt(Kfull[f:f + 1]), tt(cTw[f:f + 1]), None)
     print("fp32 vs half-model hint sampling (frame, kept, flipped, max |w-0.025| of flips, max |dw| kept):", stats)
+
+
+@pytest.mark.parametrize("programs", [False, True])
+def test_incremental_scans_in_flight_equal_the_same_scans_alone(programs):
+    """loops.run_incremental_scans (round 6): three scans of the incremental mode in flight on HIP-stream lanes, one shared
+    model (with and without launch programs).  Scans are independent, the frames of a scan are not: every scan's predicted
+    depths and its final TSDF (values, weights, active bits) must equal, bit for bit, what the scan gives when it runs alone."""
+    import gpu_util as gu
+    from doubletake_amd import loops
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
+    from doubletake_amd.tools.fusers_helper import OurFuser
+
+    dev = gu.dev()
+    hh, ww, k, D2 = 48, 64, 3, 16
+    Hh, Wh = 2 * hh, 2 * ww
+    model = DepthModelCVHint(4 * hh, 4 * ww, depth_decoder_name="skip", matching_num_depth_bins=D2, model_num_views=k + 1,
+                             matching_encoder_type=None)
+    gu.set_formula_weights(model, 9)
+    model = model.to(dev)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lengths = (5, 3, 4)
+
+    def make_scan(s, record):
+        surface, K, T = syn.tsdf_frames(lengths[s], Hh, Wh, seed=11 + s, bounds=BD)
+        batches = []
+        for f in range(lengths[s]):
+            cur = {"K_s0_b44": tt(K[f:f + 1]), "invK_s0_b44": tt(np.linalg.inv(K[f:f + 1])), "cam_T_world_b44": tt(T[f:f + 1]),
+                   "world_T_cam_b44": tt(np.linalg.inv(T[f:f + 1]).astype(np.float32)), "K_full_depth_b44": tt(K[f:f + 1]),
+                   "_t": gu.to_dev(syn.volume_inputs(1, k, hh, ww, 16, 100 * s + f)),
+                   "_pyr": [tt(p).contiguous(memory_format=torch.channels_last)
+                            for p in syn.prior_pyramid(1, [64, 64, 128, 256, 512], Hh, Wh, 100 * s + 50 + f)],
+                   "_base": tt(surface[f:f + 1] * np.float32(0.6))}
+            batches.append((cur, {}))
+
+        def model_fn(cur, src):
+            t = cur["_t"]
+            out = dict(model.forward_from_features(cur["_pyr"], t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"],
+                                                   t["src_Ks"], t["cur_invK"], cur, return_mask=True))
+            record.append(out["depth_pred_s0_b1hw"].clone())
+            out["depth_pred_s0_b1hw"] = cur["_base"] + 0.02 * torch.tanh(out["depth_pred_s0_b1hw"] - 1.0)
+            return out
+
+        fuser = OurFuser(None, 0.04, 3.0, bounds=BD)
+        return loops.IncrementalScan(model_fn, fuser, batches, (Hh, Wh)), fuser
+
+    model.enable_launch_programs(programs)
+    try:
+        alone = []
+        for s in range(3):
+            rec = []
+            scan, fuser = make_scan(s, rec)
+            while scan.step():
+                pass
+            torch.cuda.synchronize()
+            t = fuser.tsdf_fuser_pred.tsdf
+            alone.append((rec, t.tsdf_values.clone(), t.tsdf_weights.clone(), t.voxel_bitmap.clone()))
+            assert scan.frames == lengths[s] and (t.tsdf_weights > 0).sum().item() > 500
+        recs = [[], [], []]
+        built = [make_scan(s, recs[s]) for s in range(3)]
+        done = loops.run_incremental_scans([b[0] for b in built], in_flight=3, device=dev)
+        torch.cuda.synchronize()
+        assert done == list(lengths)
+        for s in range(3):
+            t = built[s][1].tsdf_fuser_pred.tsdf
+            rec0, v0, w0, a0 = alone[s]
+            assert len(recs[s]) == len(rec0) and all(torch.equal(a, b) for a, b in zip(recs[s], rec0)), s
+            assert torch.equal(t.tsdf_values.view(torch.int16), v0.view(torch.int16)), s
+            assert torch.equal(t.tsdf_weights.view(torch.int16), w0.view(torch.int16)) and torch.equal(t.voxel_bitmap, a0), s
+    finally:
+        model.enable_launch_programs(False)

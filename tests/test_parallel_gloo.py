@@ -546,3 +546,47 @@ def test_two_pass_with_four_keyframes_in_flight_on_two_ranks(tmp_path):
         for a0, a1, want in zip(r0[key], r1[key], ref):
             np.testing.assert_array_equal(np.asarray(a0).view(np.uint16), np.asarray(want).view(np.uint16))
             np.testing.assert_array_equal(np.asarray(a1).view(np.uint16), np.asarray(want).view(np.uint16))
+
+
+def _scene_inflight_worker(rank, world, port, out_dir):
+    """run_scene_sharded(..., scans_in_flight=2, make_scan_fn=...): two scans per rank and round through
+    loops.run_incremental_scans (CPU: lanes are bookkeeping), two gathers per round on every rank."""
+    _init(rank, world, port)
+
+    class FakeScan:  # the part of loops.IncrementalScan that run_incremental_scans / run_scene_sharded use
+        def __init__(self, scene):
+            self.scene, self.frames, self.fuser, self.left = scene, 0, _FakeFuser(scene), SCENE_FRAMES[scene]
+
+        def step(self):
+            if self.left == 0:
+                return False
+            order.append(self.scene)
+            self.left -= 1
+            self.frames += 1
+            return True
+
+    got, order = {}, []
+    mine = par.run_scene_sharded(SCENE_FRAMES, None, world, rank, on_scene_done=lambda s, d: got.__setitem__(s, d), device="cpu",
+                                 scans_in_flight=2, make_scan_fn=FakeScan)
+    torch.save({"mine": mine, "got": got, "order": order}, os.path.join(out_dir, f"scenes_if{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_scene_shard_with_two_scans_in_flight(tmp_path):
+    world = 2
+    _spawn(_scene_inflight_worker, world, str(tmp_path))
+    res = [torch.load(os.path.join(tmp_path, f"scenes_if{r}.pt"), weights_only=False) for r in range(world)]
+    plan = par.shard_scenes(SCENE_FRAMES, world)
+    assert [r["mine"] for r in res] == plan
+    # every scan ran to its end, two of a rank's scans at a time, frames of a pair interleaved round-robin
+    for r in range(world):
+        assert sorted(res[r]["order"]) == sorted(s for s in plan[r] for _ in range(SCENE_FRAMES[s]))
+        first_pair = plan[r][:2]
+        if len(first_pair) == 2:
+            head = res[r]["order"][:2 * min(SCENE_FRAMES[s] for s in first_pair)]
+            assert head == first_pair * (len(head) // 2)
+    # rank 0 received every scan's TSDF, bit for bit
+    assert sorted(res[0]["got"]) == list(range(len(SCENE_FRAMES))) and not res[1]["got"]
+    for s, d in res[0]["got"].items():
+        ref = _FakeTsdf(s)
+        assert torch.equal(d["tsdf_values"], ref.tsdf_values) and torch.equal(d["tsdf_weights"], ref.tsdf_weights)
