@@ -223,7 +223,7 @@ class _HotPathDepthModel(nn.Module):
         return feats[:, 0], feats[:, 1:].contiguous()
 
     def _cache_token(self, image_shape_chw, device):
-        return (tuple((p.data_ptr(), p._version) for p in self.matching_model.parameters()), tuple(image_shape_chw), str(device))
+        return (self._param_token("_mt_cache", ("matching_model",)), tuple(image_shape_chw), str(device))
 
     @torch.no_grad()
     def prefetch_matching_feats(self, image_n3hw, frame_ids, scan_ids=None, stream=None):
@@ -363,7 +363,11 @@ class _HotPathDepthModel(nn.Module):
         step is one C call): the walk is cached as the lists of (``_modules`` dict, name, child) and (``_parameters`` dict,
         name, parameter) edges it followed, and a call first checks that every edge still holds the same object -- a parameter
         or submodule assigned since then fails the check and triggers a new walk."""
-        c = self.__dict__.get("_wt_cache")
+        return self._param_token("_wt_cache", ("cost_volume", "cost_volume_net", "depth_decoder"))
+
+    def _param_token(self, slot, root_names):
+        """(data_ptr, version) of every parameter below the named child modules, from a cached walk (see _weights_token)."""
+        c = self.__dict__.get(slot)
         if c is not None:
             for d, k, obj in c[0]:
                 if d.get(k) is not obj:
@@ -371,11 +375,10 @@ class _HotPathDepthModel(nn.Module):
                     break
         if c is None:
             edges, params = [], []
-            roots = [(self._modules, n) for n in ("cost_volume", "cost_volume_net", "depth_decoder")]
             stack = []
-            for d, n in roots:
-                m = d.get(n)
-                edges.append((d, n, m))
+            for n in root_names:
+                m = self._modules.get(n)
+                edges.append((self._modules, n, m))
                 if m is not None:
                     stack.append(m)
             seen = set()
@@ -392,7 +395,7 @@ class _HotPathDepthModel(nn.Module):
                     edges.append((m._modules, n, ch))
                     if ch is not None:
                         stack.append(ch)
-            c = self.__dict__["_wt_cache"] = (edges, params)
+            c = self.__dict__[slot] = (edges, params)
         return tuple((p.data_ptr(), p._version) for p in c[1])
 
     def _encode(self, images_n3hw):
@@ -402,7 +405,7 @@ class _HotPathDepthModel(nn.Module):
         if g is None:
             g = getattr(self, "_graphed_encoder", None)
         if g is not None and images_n3hw.shape[0] == 1:
-            token = tuple((p.data_ptr(), p._version) for p in self.matching_model.parameters())
+            token = self._param_token("_mt_cache", ("matching_model",))
             if getattr(self, "_encoder_token", token) != token:
                 g.reset()
             self._encoder_token = token
