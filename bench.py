@@ -780,6 +780,8 @@ def main():
                 sl = wrap_index[j0] = torch.as_tensor([(j0 + i) % POOL for i in range(b)], device=device)
         return out["depth_pred_s0_b1hw"], K_pool16[sl], T_pool16[sl]
 
+    trace = (lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)) if os.environ.get("DT_BENCH_TRACE") else (lambda m: None)
+    wrap_index = {}
     pipe = make_pipeline(args.streams)
 
     pace_s = float(os.environ.get("DT_BENCH_PACE_MS", "0")) * 1e-3  # experiment hook: minimum host time between two submissions
@@ -797,10 +799,15 @@ def main():
     # hipMalloc inside the timed region (770 instead of 788 frames/s at the driver's --steps 20 --warmup 5)
     for i in range(2 * pipe.in_flight):
         step(i)
+        if os.environ.get("DT_BENCH_TRACE"):
+            torch.cuda.synchronize(device)
+            trace(f"set-up step {i} done")
     torch.cuda.synchronize(device)
+    trace("set-up done")
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(device)
+    trace("warm-up done")
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -821,6 +828,7 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     cvmod.FeatureVolumeManager._event_hook = None
+    trace("timed region done")
 
     if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -882,6 +890,7 @@ def main():
     single = None
     if args.streams > 1:  # (--streams 1: the timed region itself is the strictly sequential run)
         single = side_leg(1, args.warmup + 2 * args.steps + 200)
+    trace("side legs done")
     main_max_lead = pipe.max_lead
     main_plan_mask = pipe.conv_plan_mask if pipe.conv_plan_mask is not None else int(os.environ.get("DT_CONV_OBJ", "0"))
     pipe.close()

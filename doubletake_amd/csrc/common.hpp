@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstddef>
 #include <tuple>
+#include <type_traits>
 #include <utility>
 
 #include "../../include/doubletake_hip.h"
@@ -41,7 +43,46 @@ int conv_plan_objective_value();
 int mlp_cu_budget_value();
 bool recording_on(hipStream_t s);  // this thread records launches of stream s
 void record_node(const void* func, dim3 grid, dim3 block, size_t shmem, int nargs, const void* const* arg_ptrs,
-                 const size_t* arg_sizes, const size_t* arg_aligns);
+                 const size_t* arg_sizes, const size_t* arg_aligns, const int* arg_nptrs, const size_t* ptr_offsets);
+
+// Where the DEVICE POINTERS of a kernel argument sit (byte offsets inside the argument): a launch program patches the pointers
+// that refer to the step's input tensors, and it must know them by position -- a scan of the argument bytes for "words that look
+// like an input address" also hits padding bytes of by-value structs (uninitialised: often the upper half of a pointer that
+// lived in the same stack slot), which made one recording in ~40 patch a non-pointer word (round 6: intermittent GPU memory
+// faults on a program's first replay).  Scalars have none, a pointer parameter has one at offset 0, and every struct that is
+// passed to a kernel by value declares its own with DT_ARG_POINTERS / DT_ARG_NO_POINTERS next to its definition (the build
+// fails for a struct that does not).
+constexpr int kMaxArgPointers = 64;
+template <typename T, typename Enable = void>
+struct arg_pointers {
+  static_assert(!std::is_class_v<T> && !std::is_union_v<T>,
+                "a struct passed by value to a kernel must declare its pointer members: DT_ARG_POINTERS(T, offsets...) or "
+                "DT_ARG_NO_POINTERS(T)");
+  static int collect(size_t*) { return 0; }
+};
+template <typename T>
+struct arg_pointers<T*, void> {
+  static int collect(size_t* out) {
+    out[0] = 0;
+    return 1;
+  }
+};
+#define DT_ARG_POINTERS(T, ...)                                      \
+  template <>                                                        \
+  struct arg_pointers<T, void> {                                     \
+    static int collect(size_t* out) {                                \
+      const size_t offs[] = {__VA_ARGS__};                           \
+      int n = 0;                                                     \
+      for (size_t o : offs) out[n++] = o;                            \
+      static_assert(sizeof(offs) / sizeof(offs[0]) <= (size_t)kMaxArgPointers, "too many pointer members"); \
+      return n;                                                      \
+    }                                                                \
+  }
+#define DT_ARG_NO_POINTERS(T)                    \
+  template <>                                    \
+  struct arg_pointers<T, void> {                 \
+    static int collect(size_t*) { return 0; }    \
+  }
 
 template <typename... P, typename... A>
 inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t shmem, hipStream_t s, A&&... a) {
@@ -53,9 +94,13 @@ inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t shmem, hi
     const void* ptrs[n > 0 ? n : 1];
     const size_t sizes[n > 0 ? n : 1] = {sizeof(P)...};
     const size_t aligns[n > 0 ? n : 1] = {alignof(P)...};
+    int nptrs[n > 0 ? n : 1];
+    size_t poffs[(n > 0 ? n : 1) * kMaxArgPointers];
     int i = 0;
     std::apply([&](const auto&... v) { ((ptrs[i++] = static_cast<const void*>(&v)), ...); }, vals);
-    record_node(reinterpret_cast<const void*>(kernel), grid, block, shmem, n, ptrs, sizes, aligns);
+    int j = 0;
+    ((nptrs[j] = arg_pointers<std::remove_cv_t<P>>::collect(poffs + j * kMaxArgPointers), ++j), ...);
+    record_node(reinterpret_cast<const void*>(kernel), grid, block, shmem, n, ptrs, sizes, aligns, nptrs, poffs);
   }
   hipLaunchKernelGGL(kernel, grid, block, shmem, s, std::forward<A>(a)...);
 }

@@ -59,6 +59,10 @@ struct ConvArgs {
   unsigned long long* timing;
 #endif
 };
+// (device pointers of the argument block, by position: what a launch program may patch -- common.hpp arg_pointers)
+DT_ARG_POINTERS(ConvArgs, offsetof(ConvArgs, src) + 0 * sizeof(const float*), offsetof(ConvArgs, src) + 1 * sizeof(const float*),
+                offsetof(ConvArgs, src) + 2 * sizeof(const float*), offsetof(ConvArgs, wp), offsetof(ConvArgs, bias),
+                offsetof(ConvArgs, res), offsetof(ConvArgs, out), offsetof(ConvArgs, part_buf), offsetof(ConvArgs, part_cnt));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Hand-off of a partial output block between workgroups of ONE launch.  The per-CU L1 is never refreshed by other CUs'

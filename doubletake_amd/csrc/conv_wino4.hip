@@ -67,6 +67,11 @@ struct Args {
   int co_blocks;
   int tiles_x, tiles_y;  // 16x16-pixel output blocks
 };
+}  // namespace w4
+DT_ARG_POINTERS(w4::Args, offsetof(w4::Args, src) + 0 * sizeof(const float*), offsetof(w4::Args, src) + 1 * sizeof(const float*),
+                offsetof(w4::Args, src) + 2 * sizeof(const float*), offsetof(w4::Args, wp), offsetof(w4::Args, bias),
+                offsetof(w4::Args, res), offsetof(w4::Args, out));
+namespace w4 {
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == DT_ACT_LRELU02) return v >= 0.f ? v : 0.2f * v;

@@ -54,6 +54,11 @@ struct Args {
   int groups;  // 16-channel input groups over all sources
   int co_blocks;
 };
+}  // namespace ws
+DT_ARG_POINTERS(ws::Args, offsetof(ws::Args, src) + 0 * sizeof(const float*), offsetof(ws::Args, src) + 1 * sizeof(const float*),
+                offsetof(ws::Args, src) + 2 * sizeof(const float*), offsetof(ws::Args, wp), offsetof(ws::Args, bias),
+                offsetof(ws::Args, res), offsetof(ws::Args, out));
+namespace ws {
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == DT_ACT_LRELU02) return v >= 0.f ? v : 0.2f * v;

@@ -94,6 +94,10 @@ struct MlpArgs {
   const int* span_bounds; // [gridDim.x * NWAVES + 1] first unit of every wave's span from the cost-aware plan, or null (even / weighted split)
   int old_share_q16;      // share (x 65536) of a workgroup's units that its older four waves take (32768 = even split)
 };
+DT_ARG_POINTERS(MlpArgs, offsetof(MlpArgs, cur), offsetof(MlpArgs, src), offsetof(MlpArgs, params), offsetof(MlpArgs, w1dyn),
+                offsetof(MlpArgs, w1pix), offsetof(MlpArgs, w2p), offsetof(MlpArgs, tail), offsetof(MlpArgs, hint_mlp),
+                offsetof(MlpArgs, hint_d), offsetof(MlpArgs, hint_w), offsetof(MlpArgs, hint_m), offsetof(MlpArgs, vol),
+                offsetof(MlpArgs, tile_order), offsetof(MlpArgs, span_bounds));
 
 // LeakyReLU(0.01) in two vector instructions: max(x, 0.01 x) == med3(x, 0.01 x, +inf) exactly; fmaxf() costs a third one
 // (it canonicalises x first).  pinf must be an OPAQUE +inf (see the kernel): a literal is folded back into fmaxf().

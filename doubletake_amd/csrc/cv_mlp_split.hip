@@ -70,6 +70,11 @@ struct Args {
   int num_tiles;
   long total_units;
 };
+}  // namespace sp
+DT_ARG_POINTERS(sp::Args, offsetof(sp::Args, cur), offsetof(sp::Args, src), offsetof(sp::Args, params), offsetof(sp::Args, w1dyn),
+                offsetof(sp::Args, w1pix), offsetof(sp::Args, w2), offsetof(sp::Args, tail), offsetof(sp::Args, hint_mlp),
+                offsetof(sp::Args, hint_d), offsetof(sp::Args, hint_w), offsetof(sp::Args, hint_m), offsetof(sp::Args, vol));
+namespace sp {
 
 struct ViewData {
   float4 t00a, t00b, t01a, t01b, t10a, t10b, t11a, t11b;

@@ -80,6 +80,7 @@ __device__ __forceinline__ int reflect(int i, int n) {
 struct BlurFilt {
   float f[16];
 };
+DT_ARG_NO_POINTERS(BlurFilt);
 __global__ __launch_bounds__(256) void blurpool_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h,
                                                       int w, int c, int ho, int wo, BlurFilt filt) {
   const int c4 = c >> 2;

@@ -22,6 +22,10 @@ struct HeadArgs {
   long pixels;
   int cin;
 };
+#define DT_HEAD_ARG_PTRS(BASE)                                                                                              \
+  (BASE) + offsetof(HeadArgs, in), (BASE) + offsetof(HeadArgs, wa), (BASE) + offsetof(HeadArgs, wb), (BASE) + offsetof(HeadArgs, tail), \
+      (BASE) + offsetof(HeadArgs, out), (BASE) + offsetof(HeadArgs, out_exp)
+DT_ARG_POINTERS(HeadArgs, DT_HEAD_ARG_PTRS(0));
 
 __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : __expf(v) - 1.0f; }  // ATen: exp(x) - 1
 
@@ -97,6 +101,11 @@ struct HeadMultiArgs {
   HeadArgs h[kHeadMultiMax];
   unsigned first[kHeadMultiMax + 1];  // tile prefix: head i owns virtual blocks [first[i], first[i+1])
 };
+static_assert(kHeadMultiMax == 4, "DT_ARG_POINTERS(HeadMultiArgs) lists four heads");
+DT_ARG_POINTERS(HeadMultiArgs, DT_HEAD_ARG_PTRS(offsetof(HeadMultiArgs, h) + 0 * sizeof(HeadArgs)),
+                DT_HEAD_ARG_PTRS(offsetof(HeadMultiArgs, h) + 1 * sizeof(HeadArgs)),
+                DT_HEAD_ARG_PTRS(offsetof(HeadMultiArgs, h) + 2 * sizeof(HeadArgs)),
+                DT_HEAD_ARG_PTRS(offsetof(HeadMultiArgs, h) + 3 * sizeof(HeadArgs)));
 
 constexpr long kHeadSplitMaxTiles = 1024;
 

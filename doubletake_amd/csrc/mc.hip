@@ -41,6 +41,7 @@ struct McArgs {
   float iso;
   int mn[3], mx[3];
 };
+DT_ARG_POINTERS(McArgs, offsetof(McArgs, vol), offsetof(McArgs, active));
 
 // corner code c = dx + 2*dy + 4*dz (dx along Z/k, dy along Y/j, dz along X/i) -> Bourke corner vi
 __device__ __constant__ const unsigned char kCodeToVi[8] = {0, 1, 4, 5, 3, 2, 7, 6};
@@ -326,6 +327,7 @@ struct McRasterArgs {
   int h, w;
   uint32_t* zb;
 };
+DT_ARG_POINTERS(McRasterArgs, offsetof(McRasterArgs, cam_T_world), offsetof(McRasterArgs, K), offsetof(McRasterArgs, zb));
 
 __global__ __launch_bounds__(256) void mc_raster_kernel(const McArgs a, const McRasterArgs r) {
   __shared__ int lds[256];

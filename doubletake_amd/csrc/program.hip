@@ -10,7 +10,8 @@
 // How.  dt_program_begin(stream) puts the calling thread in recording mode for that stream.  Every launch the library then
 // makes on it (dt::launch in common.hpp, under every entry point) still executes and is appended to the program; launches on
 // other streams are not touched.  dt_program_input registers the device ranges that will differ between replays (the
-// step's input tensors): at dt_program_end every 8-byte-aligned argument word that points into such a range becomes a
+// step's input tensors): at dt_program_end every POINTER of the recorded arguments (pointer parameters, and the pointer members
+// that by-value argument structs declare with DT_ARG_POINTERS: common.hpp) that points into such a range becomes a
 // patch (slot, offset), and dt_program_launch rewrites those words from the pointers it is given.  Everything else the
 // recorded launches point at -- intermediates, outputs, packed weights, the library's per-stream scratch -- must stay
 // allocated for the life of the program: the caller records into buffers it keeps (utils/program.py: a private memory pool).
@@ -50,11 +51,13 @@ struct Program {
   int device = 0;
   std::vector<ProgNode> nodes;
   std::vector<unsigned> arg_off;         // blob offset of every argument of every node
+  std::vector<unsigned> ptr_off;         // blob offsets of the words that ARE device pointers (declared per argument type)
   std::vector<char> blob;                // argument bytes (16-byte aligned base: std::vector<char> of an over-aligned chunk)
   std::vector<void*> arg_ptrs;           // built at end(): &blob[arg_off[i]]
   std::vector<ProgInput> inputs;
   std::vector<ProgPatch> patches;
   std::vector<unsigned> seg_begin;       // node index at which segment i starts (seg_begin[0] = 0)
+  long lookalikes = 0;                   // see dt_program_end
 };
 
 static thread_local Program* t_rec = nullptr;
@@ -65,7 +68,7 @@ static std::set<Program*> g_programs;  // live handles (dt_program_launch / _fre
 bool recording_on(hipStream_t s) { return t_rec != nullptr && t_rec->stream == s; }
 
 void record_node(const void* func, dim3 grid, dim3 block, size_t shmem, int nargs, const void* const* arg_ptrs,
-                 const size_t* arg_sizes, const size_t* arg_aligns) {
+                 const size_t* arg_sizes, const size_t* arg_aligns, const int* arg_nptrs, const size_t* ptr_offsets) {
   Program* p = t_rec;
   ProgNode n;
   n.func = func;
@@ -75,14 +78,14 @@ void record_node(const void* func, dim3 grid, dim3 block, size_t shmem, int narg
   n.arg_begin = (unsigned)p->arg_off.size();
   n.nargs = (unsigned)nargs;
   for (int i = 0; i < nargs; ++i) {
-    // every argument starts at a multiple of max(its alignment, 8): pointer members of by-value structs then sit on 8-byte
-    // aligned blob offsets, which is what the patch scan walks
     const size_t al = arg_aligns[i] > 8 ? arg_aligns[i] : 8;
     size_t off = (p->blob.size() + al - 1) / al * al;
     const size_t padded = (arg_sizes[i] + 7) / 8 * 8;
     p->blob.resize(off + padded, 0);
     memcpy(p->blob.data() + off, arg_ptrs[i], arg_sizes[i]);
     p->arg_off.push_back((unsigned)off);
+    // the pointer members of this argument, by position (common.hpp: arg_pointers) -- the only words a patch may touch
+    for (int k = 0; k < arg_nptrs[i]; ++k) p->ptr_off.push_back((unsigned)(off + ptr_offsets[(size_t)i * kMaxArgPointers + k]));
   }
   p->nodes.push_back(n);
 }
@@ -162,9 +165,9 @@ int dt_program_end(dt_program_t* out) {
   }
   p->arg_ptrs.resize(p->arg_off.size());
   for (size_t i = 0; i < p->arg_off.size(); ++i) p->arg_ptrs[i] = p->blob.data() + p->arg_off[i];
-  // patch table: every 8-byte aligned argument word that points into a registered input range
+  // patch table: every declared pointer word that points into a registered input range
   if (!p->inputs.empty()) {
-    for (size_t off = 0; off + 8 <= p->blob.size(); off += 8) {
+    for (const unsigned off : p->ptr_off) {
       uint64_t v;
       memcpy(&v, p->blob.data() + off, 8);
       for (size_t s = 0; s < p->inputs.size(); ++s) {
@@ -174,6 +177,21 @@ int dt_program_end(dt_program_t* out) {
           break;
         }
       }
+    }
+  }
+  // diagnostic (dt_program_info item 5): argument words that are NOT declared pointers but whose bytes happen to lie in an input
+  // range -- what a scan of the argument bytes would have patched by mistake (struct padding, two adjacent 32-bit fields)
+  if (!p->inputs.empty()) {
+    std::set<unsigned> declared(p->ptr_off.begin(), p->ptr_off.end());
+    for (size_t off = 0; off + 8 <= p->blob.size(); off += 8) {
+      if (declared.count((unsigned)off)) continue;
+      uint64_t v;
+      memcpy(&v, p->blob.data() + off, 8);
+      for (const ProgInput& in : p->inputs)
+        if (v >= in.base && v < in.base + (uint64_t)in.bytes) {
+          ++p->lookalikes;
+          break;
+        }
     }
   }
   {
@@ -227,6 +245,7 @@ int64_t dt_program_info(dt_program_t h, int what) {
     case 2: return (int64_t)p->patches.size();
     case 3: return (int64_t)p->inputs.size();
     case 4: return (int64_t)p->blob.size();
+    case 5: return (int64_t)p->lookalikes;
     default: fail("dt_program_info: unknown item %d", what); return -1;
   }
 }

@@ -37,6 +37,8 @@ struct SpGrid {
   int* count;          // [0] allocated blocks, [1] blocks that did not fit / fell outside the directory (error flag)
   int cap;
 };
+DT_ARG_POINTERS(SpGrid, offsetof(SpGrid, dir), offsetof(SpGrid, touch), offsetof(SpGrid, keys), offsetof(SpGrid, tsdf), offsetof(SpGrid, weight),
+                offsetof(SpGrid, count));
 
 struct SpCam {
   float K[9];    // intrinsics 3x3
@@ -54,6 +56,7 @@ struct SpCamSrc {
   const float* K_dev;  // non-null: read K / T from device memory instead
   const float* T_dev;
 };
+DT_ARG_POINTERS(SpCamSrc, offsetof(SpCamSrc, K_dev), offsetof(SpCamSrc, T_dev));
 
 __host__ __device__ inline void fill_cam(SpCam& c, const float* K44, const float* T44) {
   for (int i = 0; i < 3; ++i)

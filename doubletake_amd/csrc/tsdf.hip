@@ -139,6 +139,7 @@ struct TsdfConsts {
   float depth_range;     // fp32(max_depth - min_depth)
   float img_w_h, img_h_h;  // half(W), half(H) as float
 };
+DT_ARG_NO_POINTERS(TsdfConsts);
 
 // DEPTH32: the depth maps are fp32 and rounded to half on the fly (what OurFuser.fuse_frames's .half() does,
 // tools/fusers_helper.py:67-73, without a converting copy kernel in front of every integration)

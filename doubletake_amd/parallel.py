@@ -277,6 +277,7 @@ class KeyframePipeline:
         self.streams = None
         self._fuse_done = None
         self._steps = 0
+        self._last_lane = 0
         self._prev_plan = None
         self._closed = False
         self.model = model
@@ -343,6 +344,7 @@ class KeyframePipeline:
             t0 = time.perf_counter()
             self._pending.pop(0).synchronize()
             self.host_wait_s += time.perf_counter() - t0  # (blocked on the GPU, not issuing: bench.py subtracts it)
+        self._last_lane = self.lane_of(i)
         with self.lane(i):
             res = fn()
             n = 0
@@ -385,7 +387,7 @@ class KeyframePipeline:
         integration so that it follows it), then ``drain()``.  Collective in slab mode: every rank calls it."""
         if self.shard_fuser is not None:
             if self.streams is not None and self._steps:
-                with torch.cuda.stream(self.streams[self.lane_of(self._steps - 1)]):
+                with torch.cuda.stream(self.streams[self._last_lane]):
                     if self._fuse_done is not None:
                         torch.cuda.current_stream(self.device).wait_event(self._fuse_done)
                     self.shard_fuser.gather_slabs()

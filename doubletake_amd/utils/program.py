@@ -38,6 +38,15 @@ class NotReplayable(RuntimeError):
     pass
 
 
+import contextlib as _contextlib  # noqa: E402
+import os as _os  # noqa: E402
+
+#: experiment switches of scripts/stress_program_record.py (defaults = the product behaviour)
+_USE_POOL = _os.environ.get("DT_REC_POOL", "1") != "0"
+_USE_GUARD = _os.environ.get("DT_REC_GUARD", "1") != "0"
+_USE_CHECK = _os.environ.get("DT_REC_CHECK", "1") != "0"
+
+
 class _LaunchGuard(TorchDispatchMode):
     """Collects the torch ops that produced or modified GPU data during a recording pass (anything that is neither an
     allocation nor a view)."""
@@ -78,7 +87,7 @@ class RecordedCallable:
         self.warmup = max(1, int(warmup))
         self.between = between
         self.cut_config = cut_config
-        self.check = check
+        self.check = check and _USE_CHECK
         self._entries = {}
         self.recordings = 0
         self.replays = 0
@@ -115,7 +124,8 @@ class RecordedCallable:
             _graphs._TLS.capturing = self
             _graphs._TLS.recording = True
             try:
-                with torch.cuda.use_mem_pool(pool, device=dev), guard:
+                with (torch.cuda.use_mem_pool(pool, device=dev) if _USE_POOL else _contextlib.nullcontext()), \
+                        (guard if _USE_GUARD else _contextlib.nullcontext()):
                     out = self.fn(*s_args, **s_kwargs)
             finally:
                 _graphs._TLS.capturing = None
@@ -131,7 +141,13 @@ class RecordedCallable:
                                 "replay): " + ", ".join(sorted(set(guard.offenders))))
         ent = dict(prog=prog, pool=pool, tags=tags, out=out, nseg=int(L.dt_program_info(prog, 1)), static=static,
                    slots=[i for i, t in enumerate(static) if t.numel()], stream=stream.value,
-                   launches=int(L.dt_program_info(prog, 0)), patches=int(L.dt_program_info(prog, 2)))
+                   launches=int(L.dt_program_info(prog, 0)), patches=int(L.dt_program_info(prog, 2)),
+                   lookalikes=int(L.dt_program_info(prog, 5)))
+        if ent["lookalikes"] and _os.environ.get("DT_BENCH_TRACE"):
+            import sys as _sys
+
+            print(f"[program] {ent['lookalikes']} non-pointer argument word(s) hold values inside an input range (not patched)",
+                  file=_sys.stderr, flush=True)
         ent["ptrs"] = (C.c_void_p * max(1, len(ent["slots"])))()
         self.recordings += 1
         if self.check:
@@ -143,14 +159,39 @@ class RecordedCallable:
                     o.fill_(float("nan"))
                 else:
                     o.zero_()
+            same = lambda a, b: torch.equal(a, b) or (a.is_floating_point() and torch.equal(torch.nan_to_num(a, nan=12345.0),
+                                                                                            torch.nan_to_num(b, nan=12345.0)))
             self._launch(ent, static, stream, run_between=False)
             torch.cuda.current_stream(dev).synchronize()
-            bad = [i for i, (a, b) in enumerate(zip(want, outs)) if not torch.equal(a, b) and not
-                   (a.is_floating_point() and torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)))]
+            bad = [i for i, (a, b) in enumerate(zip(want, outs)) if not same(a, b)]
             if bad:
                 L.dt_program_free(prog)
                 raise NotReplayable(f"replay of the recorded step differs from its eager execution in outputs {bad} "
                                     f"({ent['launches']} launches recorded): something in the step did not go through the library")
+            # relocation check: the same input VALUES at other addresses, with the recorded addresses poisoned -- a recorded
+            # pointer into an input that the patch table missed would read the poison, a non-pointer word that the table
+            # caught by accident would now change
+            moved = [t.clone(memory_format=torch.preserve_format) for t in static]
+            keep = [t.clone(memory_format=torch.preserve_format) for t in static]
+            for t in static:
+                if t.is_floating_point():
+                    t.fill_(float("nan"))
+                elif t.dtype != torch.bool:
+                    t.fill_(-1)
+            for o in outs:
+                if o.is_floating_point():
+                    o.fill_(float("nan"))
+                else:
+                    o.zero_()
+            self._launch(ent, moved, stream, run_between=False)
+            torch.cuda.current_stream(dev).synchronize()
+            for t, k in zip(static, keep):
+                t.copy_(k)
+            bad = [i for i, (a, b) in enumerate(zip(want, outs)) if not same(a, b)]
+            if bad:
+                L.dt_program_free(prog)
+                raise NotReplayable(f"replay on relocated inputs differs in outputs {bad}: the patch table of the program "
+                                    f"({ent['patches']} patches for {len(ent['slots'])} inputs) does not cover every use of an input")
         return ent
 
     def _launch(self, ent, tensors, stream, run_between=True):
@@ -188,7 +229,8 @@ class RecordedCallable:
 
     def info(self):
         """One dict per recorded program: launches, segments, patches, input slots."""
-        return [dict(launches=e["launches"], segments=e["nseg"], patches=e["patches"], inputs=len(e["slots"]), stream=e["stream"])
+        return [dict(launches=e["launches"], segments=e["nseg"], patches=e["patches"], inputs=len(e["slots"]), stream=e["stream"],
+                     lookalikes=e["lookalikes"])
                 for e in self._entries.values()]
 
     def reset(self):

@@ -545,15 +545,18 @@ int dt_conv2d_wino4_f32(const dt_conv_desc* d, const float* in0, const float* in
  *                              step); ranges must not overlap; returns the slot index (>= 0) or -1
  *   dt_program_mark()          segment boundary at the current position; returns the index of the segment that starts here
  *                              (segment 0 starts at dt_program_begin) or -1
- *   dt_program_end(&prog)      stops recording; every 8-byte aligned argument word that points into an input range becomes
- *                              a patch (slot, offset)
+ *   dt_program_end(&prog)      stops recording; every POINTER of the recorded arguments that points into an input range becomes a
+ *                              patch (slot, offset).  Pointers are known by position (pointer parameters; the pointer members
+ *                              every by-value argument struct declares, csrc/common.hpp DT_ARG_POINTERS) -- never guessed from
+ *                              the argument bytes, whose struct padding is uninitialised
  *   dt_program_abort()         stops recording and discards what was recorded (error paths)
  *   dt_program_launch(prog, segment, inputs, num_inputs, s)
  *                              re-issues the launches of one segment (segment = -1: all of them) on s, which must be the
  *                              stream the program was recorded on (the library's per-stream split-K scratch is baked in).
  *                              inputs[i] = this replay's address of slot i (same extents and layout as recorded); they are
  *                              applied when segment <= 0, i.e. once per replay.  One replay at a time per program.
- *   dt_program_info(prog, what) 0 launches, 1 segments, 2 patches, 3 input slots, 4 argument bytes; -1 on error
+ *   dt_program_info(prog, what) 0 launches, 1 segments, 2 patches, 3 input slots, 4 argument bytes, 5 argument words that are not
+ *                              pointers but happen to hold a value inside an input range (diagnostic: never patched); -1 on error
  *   dt_program_free(prog)
  *
  * Everything else the recorded launches point at (intermediates, outputs, packed weights) must stay allocated, at the same
