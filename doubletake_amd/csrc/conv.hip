@@ -1694,7 +1694,7 @@ int dt_conv2d_wino_f32(const dt_conv_desc* d, const float* in0, const float* in1
   return check_launch("dt_conv2d_wino_f32");
 }
 
-/* dt_conv2d_wino_f32 with n_heads fused regression heads (dt_head_mlp_multi_f32's tables) as the first workgroups of the same
+/* dt_conv2d_wino_f32 with n_heads fused regression heads (dt_head_mlp_multi_f32's tables) as the LAST workgroups (DT_HEADS_FIRST=0, the shipped order; 1 = in front) of the same
  * launch.  Only for Winograd launches of 256-thread workgroups without a K split across workgroups (the chip-filling layers);
  * anything else runs as the two launches it replaces.  Results are those of the two launches, bit for bit. */
 int dt_conv2d_wino_heads_f32(const dt_conv_desc* d, const float* in0, const float* in1, const float* in2, const float* packed_w,

@@ -309,7 +309,7 @@ int dt_head_mlp_multi_f32(int n_heads, const float* const* in_nhwc, const float*
                           float* const* out_exp, const int64_t* pixels, const int* cin, dt_stream_t s);
 /* dt_conv2d_wino_f32 and dt_head_mlp_multi_f32 in ONE launch (round 5): SkipDecoderRegression's heads of scales 3, 2, 1
  * (modules/networks_fast.py:134-141) depend on decoder features that are final before the last block's 240x320 convolutions
- * start, and nothing depends on them, so their workgroups ride at the front of that convolution's grid instead of waiting at
+ * start, and nothing depends on them, so their workgroups ride at the END of that convolution's grid (the shipped order, DT_HEADS_FIRST=0: they start as the conv's first round of workgroups drains; in front of the conv blocks measured slower) instead of waiting at
  * the end of the stream as a launch of their own (one workgroup's dependent MFMA chain long).  Arguments: those of the two
  * calls.  Only chip-filling Winograd launches (>= 2 workgroups per CU) are fused; anything else runs as the two launches.
  * Results are bit-identical to the two launches. */

@@ -508,7 +508,7 @@ def test_throughput_plan_objective_computes_the_same_graph(mask):
 
 @pytest.mark.parametrize("h0,w0,with_depth", [(120, 160, True), (96, 128, False), (16, 24, True)])
 def test_coarse_heads_inside_the_conv_grid_are_bit_identical(h0, w0, with_depth):
-    """Round 5 (dt_conv2d_wino_heads_f32): SkipDecoderRegression's heads of scales 3, 2, 1 run as the first workgroups of the
+    """Round 5 (dt_conv2d_wino_heads_f32): SkipDecoderRegression's heads of scales 3, 2, 1 run as extra workgroups (behind the conv blocks) of the
     last block's first 240x320 convolution instead of as a launch of their own.  Same bodies: every output of the decoder must
     equal the two-launch path bit for bit, and the step must need one launch less -- at bench size and at the cfg4 size; on a
     small map (the convolution does not fill the chip) the fused entry falls back to the two launches."""
