@@ -38,12 +38,9 @@ class NotReplayable(RuntimeError):
     pass
 
 
-import contextlib as _contextlib  # noqa: E402
 import os as _os  # noqa: E402
 
-#: experiment switches of scripts/stress_program_record.py (defaults = the product behaviour)
-_USE_POOL = _os.environ.get("DT_REC_POOL", "1") != "0"
-_USE_GUARD = _os.environ.get("DT_REC_GUARD", "1") != "0"
+#: DT_REC_CHECK=0 skips the two replay checks of a recording (experiment switch of the round-6 fault hunt; default on)
 _USE_CHECK = _os.environ.get("DT_REC_CHECK", "1") != "0"
 
 
@@ -124,8 +121,7 @@ class RecordedCallable:
             _graphs._TLS.capturing = self
             _graphs._TLS.recording = True
             try:
-                with (torch.cuda.use_mem_pool(pool, device=dev) if _USE_POOL else _contextlib.nullcontext()), \
-                        (guard if _USE_GUARD else _contextlib.nullcontext()):
+                with torch.cuda.use_mem_pool(pool, device=dev), guard:
                     out = self.fn(*s_args, **s_kwargs)
             finally:
                 _graphs._TLS.capturing = None
