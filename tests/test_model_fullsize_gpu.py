@@ -354,3 +354,16 @@ def test_cfg5_small_d96_whole_tensors_vs_torch_cpu_oracle():
     every element of every tensor: volume, CVEncoder maps, log depth, depth."""
     c = _whole_tensor_case("cfg5_small_d96", element=1)
     _assert_whole_tensors(c)
+
+
+def test_cfg5_full_d96_whole_tensors_vs_torch_cpu_oracle():
+    """BASELINE configs[4]'s shape with the full model (portrait 384x512, 96 planes, batch 2, DepthDecoderPP): one batch element,
+    every element of the volume, the CVEncoder maps, all ten UNet++ nodes, log depth and depth against the torch-CPU restatement."""
+    c = _whole_tensor_case("cfg5_full_d96", element=0)
+    _assert_whole_tensors(c)
+    assert len(c["nodes"]) == 10 and sorted(c["nodes_gpu"]) == sorted(c["nodes"])
+    for name, want in c["nodes"].items():
+        got = c["nodes_gpu"][name].cpu()[c["sl"]]
+        assert tuple(got.shape) == tuple(want.shape), name
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) < 2e-4 * scale, (name, float((got - want).abs().max()), scale)

@@ -184,3 +184,39 @@ def test_launch_program_refuses_steps_with_foreign_kernels():
     rc = RecordedCallable(lambda x: x * 2.0)
     with pytest.raises(NotReplayable):
         rc(torch.ones(8, device=pyr[0].device))
+
+
+@pytest.mark.parametrize("volume_type", ["mlp_feature_volume", "simple_cost_volume"])
+def test_simplerecon_model_types_replay_from_launch_programs_too(volume_type):
+    """DepthModel (SimpleRecon, reference experiment_modules/sr_depth_model.py:186-204) shares the hot-path base class: its
+    metadata-MLP volume (no hints) and its dot-product volume replay from launch programs bit-identically as well."""
+    import gpu_util as gu
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModel
+
+    h, w, k, D = 24, 32, 3, 16
+    model = DepthModel(4 * h, 4 * w, depth_decoder_name="skip", matching_num_depth_bins=D, model_num_views=k + 1,
+                       matching_encoder_type=None, feature_volume_type=volume_type)
+    gu.set_formula_weights(model, 11)
+    model = model.to(gu.dev())
+
+    def frame(s):
+        t = gu.to_dev(syn.volume_inputs(1, k, h, w, 16, s))
+        pyr = [torch.from_numpy(p).to(gu.dev()).contiguous(memory_format=torch.channels_last)
+               for p in syn.prior_pyramid(1, [64, 64, 128, 256, 512], 2 * h, 2 * w, s + 50)]
+        return t, pyr
+
+    def run(fr):
+        t, pyr = fr
+        return model.forward_from_features(pyr, t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"], t["src_Ks"],
+                                           t["cur_invK"], None, return_mask=True)
+
+    frames = [frame(70 + i) for i in range(2)]
+    want = [{kk: v.clone() for kk, v in run(f).items() if v is not None} for f in frames]
+    model.enable_launch_programs(True)
+    for f, wnt in zip(frames + frames, want + want):
+        got = run(f)
+        torch.cuda.synchronize()
+        for kk in wnt:
+            assert torch.equal(got[kk], wnt[kk]), (volume_type, kk)
+    assert model._recorded_forward.recordings == 1 and model._recorded_forward.info()[0]["lookalikes"] == 0
+    model.enable_launch_programs(False)
