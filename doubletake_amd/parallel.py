@@ -565,7 +565,7 @@ def gather_variable(payload: torch.Tensor, world: int, dst: int = 0, rank: int =
 
 
 def run_scene_sharded(frame_counts, run_scene_fn, world: int, rank: int, on_scene_done=None, device=None, scans_in_flight=1,
-                      make_scan_fn=None):
+                      make_scan_fn=None, batched_model_fn=None):
     """Incremental mode over a scan list (reference test_incremental.py:114-491, the ``for scan in scans`` loop).
 
     ``run_scene_fn(scene_index)`` runs one scan's sequential per-frame loop (hint from TSDF(t-1) -> model -> fuse,
@@ -578,7 +578,10 @@ def run_scene_sharded(frame_counts, run_scene_fn, world: int, rank: int, on_scen
     ``scans_in_flight = k > 1`` a rank takes k scans of its list per round and runs them interleaved on k HIP-stream lanes
     (``loops.run_incremental_scans``: scans are independent, one scan alone is a chain of latency-bound kernels; 721 -> 882
     frames/s per GPU at 512x384 with four, ``profiles/r6q_time_incremental_scans_program.json``), then the k finished TSDFs
-    are gathered one after the other (every rank issues k gathers per round, empty payloads where it has no scan)."""
+    are gathered one after the other (every rank issues k gathers per round, empty payloads where it has no scan).
+    With ``batched_model_fn`` the k scans of a round advance in lock step instead, their current frames evaluated by ONE
+    ``batched_model_fn(cur_data_k, src_data_k)`` call per turn (``loops.IncrementalScanBatch``: 1003 frames/s with four scans,
+    1107 with eight, ``profiles/r7b_*``; per-scan results equal the scan alone to fp32 rounding, not bit for bit)."""
     plan = shard_scenes(frame_counts, world)
     k = max(1, int(scans_in_flight)) if make_scan_fn is not None else 1
     rounds = max(((len(p) + k - 1) // k for p in plan), default=0)
@@ -590,7 +593,10 @@ def run_scene_sharded(frame_counts, run_scene_fn, world: int, rank: int, on_scen
                 from . import loops
 
                 scans = [make_scan_fn(scene) for scene in mine]
-                loops.run_incremental_scans(scans, in_flight=k, device=device)
+                if batched_model_fn is not None:
+                    loops.run_incremental_scans([loops.IncrementalScanBatch(scans, batched_model_fn)], in_flight=1, device=device)
+                else:
+                    loops.run_incremental_scans(scans, in_flight=k, device=device)
                 fusers = [(scene, sc.fuser) for scene, sc in zip(mine, scans)]
             else:
                 fusers = [(scene, run_scene_fn(scene)) for scene in mine]

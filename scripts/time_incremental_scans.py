@@ -3,7 +3,8 @@
 inside a scan frame t needs the TSDF after frame t-1, so one scan is a chain of latency-bound kernels; different scans are
 independent and share the chip.  Same per-frame work as scripts/time_incremental.py ("serial" mode: hint from the TSDF ->
 matching encoder on the new keyframe (feature cache) -> volume + CVEncoder + decoder -> fuse); S scans of N frames each, lanes =
-1, 2, 3, 4.  Wall clock over all frames, no host synchronisation inside the loop.
+1, 2, 3, 4.  Wall clock over all frames, no host synchronisation inside the loop.  Last entries ("batched", "batched_2_lanes"): the same scans in lock
+step, ONE model call per turn on their collated keyframes (loops.IncrementalScanBatch), as one batch and as two batches on two lanes.
 
     DT_CONFIG=cfg4_small python scripts/time_incremental_scans.py     (DT_FRAMES=40 per scan, DT_SCANS=4, DT_LAUNCH=program|eager)"""
 import json
@@ -30,9 +31,13 @@ class FixedPyramid(nn.Module):
     def __init__(self, pyr):
         super().__init__()
         self.pyr = pyr
+        self._by_batch = {1: pyr}
 
     def forward(self, image):
-        return self.pyr
+        b = image.shape[0]
+        if b not in self._by_batch:  # (the batched mode evaluates k scans' keyframes in one call)
+            self._by_batch[b] = [p.expand(b, -1, -1, -1).contiguous(memory_format=torch.channels_last) for p in self.pyr]
+        return self._by_batch[b]
 
 
 def main():
@@ -90,6 +95,24 @@ def main():
         res[f"lanes_{lanes}" + ("_again" if f"lanes_{lanes}" in res else "")] = {
             "frames": frames, "ms_per_frame": wall / frames * 1e3, "frames_per_s": frames / wall,
             "conv_plan_mask": conv_ops.current_plan_objective()}
+    # the same scans advanced in lock step, one model call per turn on the collated keyframes (loops.IncrementalScanBatch): one
+    # batch of all scans on one stream, then two batches of half the scans each on two lanes
+    for groups in (1, 2):
+        if groups > n_scans:
+            continue
+        conv_ops.set_plan_objective(conv_ops.PLAN_THROUGHPUT if groups > 1 else conv_ops.PLAN_LATENCY)
+        for timed in (False, True):
+            model.matching_feature_cache.clear()
+            scans = [loops.IncrementalScan(None, OurFuser(None, 0.04, 3.0, bounds=bd), scan_batches(s), (H2, W2)) for s in range(n_scans)]
+            batches = [loops.IncrementalScanBatch(scans[g::groups], model_fn) for g in range(groups)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loops.run_incremental_scans(batches, in_flight=groups, device=dev)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+        frames = sum(sc.frames for sc in scans)
+        res["batched" if groups == 1 else f"batched_{groups}_lanes"] = {
+            "frames": frames, "batch": n_scans // groups, "ms_per_frame": wall / frames * 1e3, "frames_per_s": frames / wall}
     conv_ops.set_plan_objective(conv_ops.PLAN_LATENCY)
     print(json.dumps(res))
 

@@ -260,3 +260,81 @@ def test_incremental_scans_in_flight_equal_the_same_scans_alone(programs):
             assert torch.equal(t.tsdf_weights.view(torch.int16), w0.view(torch.int16)) and torch.equal(t.voxel_bitmap, a0), s
     finally:
         model.enable_launch_programs(False)
+
+
+@pytest.mark.parametrize("programs", [False, True])
+def test_incremental_scans_batched_match_the_same_scans_alone(programs):
+    """loops.run_incremental_scans_batched (round 6): three scans of different lengths advanced in lock step, ONE model call
+    per turn on the collated frames (batch 3 -> 3 -> 3 -> 2 -> 1 as the scans finish).  The model at batch k sums its convs in
+    another order than at batch 1 (other plans), so per scan the results match the scan alone to fp32 rounding, not bit for
+    bit: predicted depths within 1e-4 relative (north-star tolerance 1e-3), the final TSDF equal except isolated voxels whose
+    fp16 thresholds the rounding crossed (< 0.2 % of the observed voxels differ by more than 0.02 in value or weight)."""
+    import gpu_util as gu
+    from doubletake_amd import loops
+    from doubletake_amd.experiment_modules.doubletake_model import DepthModelCVHint
+    from doubletake_amd.tools.fusers_helper import OurFuser
+
+    dev = gu.dev()
+    hh, ww, k, D2 = 48, 64, 3, 16
+    Hh, Wh = 2 * hh, 2 * ww
+    model = DepthModelCVHint(4 * hh, 4 * ww, depth_decoder_name="skip", matching_num_depth_bins=D2, model_num_views=k + 1,
+                             matching_encoder_type=None)
+    gu.set_formula_weights(model, 9)
+    model = model.to(dev)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lengths = (5, 3, 4)
+
+    def model_fn(cur, src):
+        t = cur["_t"]
+        out = dict(model.forward_from_features(cur["_pyr"], t["cur_feats"], t["src_feats"], t["src_extrinsics"], t["src_poses"],
+                                               t["src_Ks"], t["cur_invK"], cur, return_mask=True))
+        out["raw_depth"] = out["depth_pred_s0_b1hw"].clone()
+        out["depth_pred_s0_b1hw"] = cur["_base"] + 0.02 * torch.tanh(out["depth_pred_s0_b1hw"] - 1.0)
+        return out
+
+    def make_scan(s, record):
+        surface, K, T = syn.tsdf_frames(lengths[s], Hh, Wh, seed=11 + s, bounds=BD)
+        batches = []
+        for f in range(lengths[s]):
+            cur = {"K_s0_b44": tt(K[f:f + 1]), "invK_s0_b44": tt(np.linalg.inv(K[f:f + 1])), "cam_T_world_b44": tt(T[f:f + 1]),
+                   "world_T_cam_b44": tt(np.linalg.inv(T[f:f + 1]).astype(np.float32)), "K_full_depth_b44": tt(K[f:f + 1]),
+                   "_t": gu.to_dev(syn.volume_inputs(1, k, hh, ww, 16, 100 * s + f)),
+                   "_pyr": [tt(p).contiguous(memory_format=torch.channels_last)
+                            for p in syn.prior_pyramid(1, [64, 64, 128, 256, 512], Hh, Wh, 100 * s + 50 + f)],
+                   "_base": tt(surface[f:f + 1] * np.float32(0.6))}
+            batches.append((cur, {}))
+        fuser = OurFuser(None, 0.04, 3.0, bounds=BD)
+        scan = loops.IncrementalScan(model_fn, fuser, batches, (Hh, Wh), on_frame=lambda i, c, o: record.append(o["raw_depth"].clone()))
+        return scan, fuser
+
+    model.enable_launch_programs(programs)
+    try:
+        alone = []
+        for s in range(3):
+            rec = []
+            scan, fuser = make_scan(s, rec)
+            while scan.step():
+                pass
+            torch.cuda.synchronize()
+            t = fuser.tsdf_fuser_pred.tsdf
+            alone.append((rec, t.tsdf_values.float().clone(), t.tsdf_weights.float().clone()))
+        recs = [[], [], []]
+        built = [make_scan(s, recs[s]) for s in range(3)]
+        done = loops.run_incremental_scans_batched([b[0] for b in built], model_fn)
+        torch.cuda.synchronize()
+        assert done == list(lengths)
+        stats = []
+        for s in range(3):
+            t = built[s][1].tsdf_fuser_pred.tsdf
+            rec0, v0, w0 = alone[s]
+            assert len(recs[s]) == len(rec0)
+            rel = max(float(((a - b).abs() / b.abs().clamp_min(1.0)).max()) for a, b in zip(recs[s], rec0))
+            assert all(a.shape == b.shape == (1, 1, Hh, Wh) for a, b in zip(recs[s], rec0)) and rel <= 1e-4, (s, rel)
+            seen = (w0 > 0) | (t.tsdf_weights > 0)
+            off = seen & (((t.tsdf_values.float() - v0).abs() > 0.02) | ((t.tsdf_weights.float() - w0).abs() > 0.02))
+            frac = off.sum().item() / max(1, seen.sum().item())
+            stats.append((rel, frac, int(seen.sum())))
+            assert seen.sum().item() > 500 and frac < 2e-3, (s, frac)
+        print("batched vs alone (max rel depth diff, differing voxel fraction, observed voxels):", stats)
+    finally:
+        model.enable_launch_programs(False)

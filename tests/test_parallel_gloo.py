@@ -590,3 +590,55 @@ def test_scene_shard_with_two_scans_in_flight(tmp_path):
     for s, d in res[0]["got"].items():
         ref = _FakeTsdf(s)
         assert torch.equal(d["tsdf_values"], ref.tsdf_values) and torch.equal(d["tsdf_weights"], ref.tsdf_weights)
+
+
+def _scene_batched_worker(rank, world, port, out_dir):
+    """run_scene_sharded(..., scans_in_flight=2, make_scan_fn=..., batched_model_fn=...): the two scans of a round advance in
+    lock step through loops.IncrementalScanBatch, one model call per turn on their collated frames."""
+    _init(rank, world, port)
+
+    class FakeScan:  # the part of loops.IncrementalScan that IncrementalScanBatch uses
+        lookahead = None
+
+        def __init__(self, scene):
+            self.scene, self.frames, self.fuser, self.left, self.outs = scene, 0, _FakeFuser(scene), SCENE_FRAMES[scene], []
+
+        def begin_frame(self):
+            if self.left == 0:
+                return None
+            self.left -= 1
+            return {"scene": torch.tensor([float(self.scene)]), "scan_id_string": f"s{self.scene}"}, {}
+
+        def finish_frame(self, cur, out):
+            assert out["depth"].shape == (1,) and float(out["depth"]) == 2.0 * self.scene
+            self.frames += 1
+
+    got, calls = {}, []
+
+    def model_fn(cur, src):
+        calls.append(list(cur["scan_id_string"]))
+        return {"depth": 2.0 * cur["scene"]}
+
+    mine = par.run_scene_sharded(SCENE_FRAMES, None, world, rank, on_scene_done=lambda s, d: got.__setitem__(s, d), device="cpu",
+                                 scans_in_flight=2, make_scan_fn=FakeScan, batched_model_fn=model_fn)
+    torch.save({"mine": mine, "got": got, "calls": calls}, os.path.join(out_dir, f"scenes_b{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_scene_shard_with_two_scans_batched_per_model_call(tmp_path):
+    world = 2
+    _spawn(_scene_batched_worker, world, str(tmp_path))
+    res = [torch.load(os.path.join(tmp_path, f"scenes_b{r}.pt"), weights_only=False) for r in range(world)]
+    plan = par.shard_scenes(SCENE_FRAMES, world)
+    assert [r["mine"] for r in res] == plan
+    for r in range(world):
+        want = []
+        for i in range(0, len(plan[r]), 2):
+            pair = plan[r][i:i + 2]
+            for turn in range(max(SCENE_FRAMES[s] for s in pair)):  # the batch shrinks when the shorter scan of a pair ends
+                want.append([f"s{s}" for s in pair if SCENE_FRAMES[s] > turn])
+        assert res[r]["calls"] == want
+    assert sorted(res[0]["got"]) == list(range(len(SCENE_FRAMES))) and not res[1]["got"]
+    for s, d in res[0]["got"].items():
+        ref = _FakeTsdf(s)
+        assert torch.equal(d["tsdf_values"], ref.tsdf_values) and torch.equal(d["tsdf_weights"], ref.tsdf_weights)
