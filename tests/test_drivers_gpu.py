@@ -379,3 +379,55 @@ def test_hip_graph_replay_equals_eager_launches():
                                             src_ids=frames[1][1]["frame_id_string"])
     torch.cuda.synchronize()
     assert torch.equal(m_cur, ref_feats)
+
+
+def test_one_model_call_on_keyframes_of_different_scans_with_the_feature_cache():
+    """What loops.IncrementalScanBatch asks of the model (round 6): ONE ``model("test", ...)`` call on a batch whose elements are
+    the current keyframes of DIFFERENT scans -- per-element cameras, hints, frame ids and scan ids (a list), source features
+    served from the HBM feature cache under (scan, frame) keys -- gives every element what the same frame gives in a batch-1
+    call of its own scan (fp32 rounding of the batched conv plans: depth within 1e-4 relative), over two turns so that the second
+    turn's sources are cache hits written by the first."""
+    import gpu_util as gu
+    from doubletake_amd import loops
+    from doubletake_amd.utils.rendering_utils import empty_hint
+
+    dev = gu.dev()
+    H, W, k, D = 128, 160, 3, 16
+    model = _model(H, W, k, D, dev)
+    model.use_feature_cache = True
+    cams = _cams(4, H // 2, W // 2)
+
+    def frame(scan, f):
+        cur, src = _batch(2 * scan + f, 1, k, H, W, dev, cams)   # (other images and another camera per scan and frame)
+        empty_hint(cur, torch.zeros(1, 1, H // 2, W // 2, device=dev))
+        cur["depth_hint_b1hw"] = torch.full_like(cur["depth_hint_b1hw"], 1.0 + 0.2 * scan + 0.1 * f)
+        cur["depth_hint_mask_b1hw"] = torch.ones_like(cur["depth_hint_mask_b1hw"])
+        cur["sampled_weights_b1hw"] = torch.full_like(cur["sampled_weights_b1hw"], 0.3 + 0.1 * scan)
+        cur["frame_id_string"] = [f"{10 + f:06d}"]                 # the SAME frame ids in both scans: only the scan id differs
+        cur["scan_id_string"] = f"scan{scan}"
+        src["frame_id_string"] = [[f"{10 + f - 1 - i:06d}"] for i in range(k)]
+        return cur, src
+
+    keys = [f"depth_pred_s{i}_b1hw" for i in range(4)] + ["lowest_cost_bhw"]
+    model.matching_feature_cache.clear()
+    alone = {}
+    for scan in range(2):
+        for f in range(2):
+            out = model("test", *frame(scan, f), return_mask=True)
+            alone[scan, f] = {kk: out[kk].clone() for kk in keys}
+    entries_alone = len(model.matching_feature_cache)
+    model.matching_feature_cache.clear()
+    for f in range(2):
+        items = [frame(scan, f) for scan in range(2)]
+        cur = loops._collate_frames([it[0] for it in items])
+        src = loops._collate_frames([it[1] for it in items])
+        assert cur["scan_id_string"] == ["scan0", "scan1"] and cur["image_b3hw"].shape[0] == 2 and src["image_b3hw"].shape[:2] == (2, k)
+        out = model("test", cur, src, return_mask=True)
+        for scan in range(2):
+            for kk in keys:
+                a, b = out[kk][scan:scan + 1], alone[scan, f][kk]
+                rel = float(((a - b).abs() / b.abs().clamp_min(1.0)).max())
+                assert a.shape == b.shape and rel <= 1e-4, (f, scan, kk, rel)
+    assert len(model.matching_feature_cache) == entries_alone   # the same (scan, frame) entries, no cross-scan sharing
+    # the two scans' predictions differ from each other (the test would also pass on a model that ignored its inputs otherwise)
+    assert float((alone[0, 1]["depth_pred_s0_b1hw"] - alone[1, 1]["depth_pred_s0_b1hw"]).abs().max()) > 1e-3
